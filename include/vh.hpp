@@ -1,0 +1,310 @@
+// vh.hpp -- C++ host classes of the MI355X voxel-hashing engine.
+//
+// Same class names, constructors and public methods as the reference's
+// CUDASceneRepHashSDF (DSC/CUDASceneRepHashSDF.h:28-350), CUDARayCastSDF
+// (DSC/CUDARayCastSDF.h:13-69) and CUDASceneRepChunkGrid
+// (DSC/CUDASceneRepChunkGrid.h:152-753), so the reference's frame loop
+// (DSC/DepthSensing.cpp:720-924) compiles against them after swapping the
+// includes.  Differences, all forced by dropping Windows/D3D/mLib:
+//   - mat4f / vec3f / vec3i are small PODs defined here (row-major 4x4);
+//   - GlobalAppState is gone: the five flags it supplied are a VhSceneOptions;
+//   - DepthCameraParams is passed explicitly where the reference read the
+//     process-global __constant__ c_depthCameraParams;
+//   - errors throw vh::Error (the reference aborts via cutilSafeCall/exit);
+//   - a HIP stream can be given; all work of one instance is issued on it.
+//
+// This header needs no HIP headers; link against libvoxelhashing_amd.so.
+//   DSC/ = /root/reference/DepthSensingCUDA/Source/
+#ifndef VH_HPP
+#define VH_HPP
+
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "vh_api.h"
+
+typedef VhHashEntry HashEntry;
+typedef VhVoxel Voxel;
+typedef VhHashParams HashParams;
+typedef VhHashData HashData;
+typedef VhDepthCameraParams DepthCameraParams;
+typedef VhDepthCameraData DepthCameraData;
+typedef VhRayCastParams RayCastParams;
+typedef VhRayCastData RayCastData;
+typedef VhSDFBlockDesc SDFBlockDesc;
+
+namespace vh {
+
+struct Error : public std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+struct vec3f { float x, y, z; };
+struct vec3i { int x, y, z; };
+
+// Row-major 4x4, entries m[0..15] = m11,m12,...,m44 (the layout of the
+// reference's float4x4 / mLib mat4f).
+struct mat4f {
+    float m[16];
+    static mat4f identity();
+    mat4f getInverse() const; // float4x4::getInverse, DSC/cuda_SimpleMatrixUtil.h:944-1069
+    mat4f operator*(const mat4f& o) const;
+    vec3f transformPoint(const vec3f& p) const; // float4x4 * float3, :900-907
+    float& operator()(int r, int c) { return m[4 * r + c]; }
+    float operator()(int r, int c) const { return m[4 * r + c]; }
+};
+
+struct SDFBlock { // DSC/CUDASceneRepChunkGrid.h:11-21
+    Voxel data[VH_SDF_BLOCK_VOXELS];
+};
+
+} // namespace vh
+
+struct VhStageTimer; // opaque: per-stage HIP event pairs
+
+// ---------------------------------------------------------------------------
+class CUDASceneRepHashSDF {
+public:
+    explicit CUDASceneRepHashSDF(const HashParams& params);
+    CUDASceneRepHashSDF(const HashParams& params, const VhSceneOptions& options, vhStream_t stream = nullptr);
+    ~CUDASceneRepHashSDF();
+    CUDASceneRepHashSDF(const CUDASceneRepHashSDF&) = delete;
+    CUDASceneRepHashSDF& operator=(const CUDASceneRepHashSDF&) = delete;
+
+    static VhSceneOptions defaultOptions();
+
+    // no-op kept for source compatibility (DSC/CUDASceneRepHashSDF.h:60-62)
+    void bindDepthCameraTextures(const DepthCameraData&) {}
+
+    // DSC/CUDASceneRepHashSDF.h:64-83
+    void integrate(const vh::mat4f& lastRigidTransform, const DepthCameraData& depthCameraData,
+                   const DepthCameraParams& depthCameraParams, const unsigned int* d_bitMask);
+    void setLastRigidTransform(const vh::mat4f& lastRigidTransform);                       // :85
+    void setLastRigidTransformAndCompactify(const vh::mat4f& lastRigidTransform,
+                                            const DepthCameraParams& depthCameraParams);   // :90
+    const vh::mat4f getLastRigidTransform() const;                                         // :96
+    void reset();                                                                          // :101
+    HashData& getHashData() { return m_hashData; }                                         // :112
+    // m_numOccupiedBlocks is exact in offline mode; in online mode it is the
+    // most recent count whose asynchronous read-back has completed.
+    const HashParams& getHashParams();                                                     // :116
+    unsigned int getHeapFreeCount();                                                       // :122 (blocking)
+    unsigned int getNumOccupiedBlocks();                                                   // blocking, exact
+    // :129-233; throws vh::Error on a violated invariant.  report = {numOccupied, numFree, duplicates, lockEntries}
+    void debugHash(unsigned int report[4] = nullptr);
+
+    // additions
+    void setOptions(const VhSceneOptions& o) { m_options = o; }
+    const VhSceneOptions& getOptions() const { return m_options; }
+    vhStream_t getStream() const { return m_stream; }
+    int32_t nextLockToken(); // fresh bucket-lock epoch (replaces resetHashBucketMutexCUDA)
+    void getState(uint32_t out[VH_STATE_WORDS]);
+    void getTimings(double out[4]); // ms: alloc, compactify, integrate(+gc), frames
+    unsigned int getNumIntegratedFrames() const { return m_numIntegratedFrames; }
+
+private:
+    void create(const HashParams& params);
+    void destroy();
+    void alloc(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask); // :247
+    void compactifyHashEntries(const DepthCameraParams&);                                        // :282
+    void integrateDepthMap(const DepthCameraData&, const DepthCameraParams&);                    // :317
+    void garbageCollect(const DepthCameraParams&);                                               // :327
+    void pollOccupiedCount(bool block);
+
+    HashParams m_hashParams;
+    HashData m_hashData;
+    VhSceneOptions m_options;
+    vhStream_t m_stream;
+    unsigned int m_numIntegratedFrames;
+    int32_t m_lockEpoch;
+    uint32_t* h_occupied;     // pinned: async read-back of d_hashCompactifiedCounter
+    void* m_occupiedEvent;    // hipEvent_t
+    bool m_occupiedPending;
+    VhStageTimer* m_timer;
+};
+
+// ---------------------------------------------------------------------------
+class CUDARayCastSDF {
+public:
+    explicit CUDARayCastSDF(const RayCastParams& params, vhStream_t stream = nullptr);
+    ~CUDARayCastSDF();
+    CUDARayCastSDF(const CUDARayCastSDF&) = delete;
+    CUDARayCastSDF& operator=(const CUDARayCastSDF&) = delete;
+
+    // DSC/CUDARayCastSDF.cpp:38-72.  The reference skips the view-matrix
+    // update while hashParams.m_numOccupiedBlocks == 0 (stale matrices); here
+    // the given transform is always used.
+    void render(const HashData& hashData, const HashParams& hashParams, const DepthCameraParams& cameraParams,
+                const vh::mat4f& lastRigidTransform);
+    const RayCastData& getRayCastData() { return m_data; }        // :42
+    const RayCastParams& getRayCastParams() const { return m_params; } // :45
+
+    void setTiming(bool on);
+    void getTimings(double out[3]); // ms: raycast, normals, frames
+
+private:
+    RayCastParams m_params;
+    RayCastData m_data;
+    vhStream_t m_stream;
+    VhStageTimer* m_timer;
+};
+
+// ---------------------------------------------------------------------------
+class ChunkDesc { // DSC/CUDASceneRepChunkGrid.h:68-121
+public:
+    explicit ChunkDesc(unsigned int initialChunkListSize)
+    {
+        m_SDFBlocks.reserve(initialChunkListSize);
+        m_ChunkDesc.reserve(initialChunkListSize);
+    }
+    void addSDFBlock(const SDFBlockDesc& desc, const vh::SDFBlock& data)
+    {
+        m_ChunkDesc.push_back(desc);
+        m_SDFBlocks.push_back(data);
+    }
+    unsigned int getNElements() const { return (unsigned int)m_SDFBlocks.size(); }
+    void clear() { m_ChunkDesc.clear(); m_SDFBlocks.clear(); }
+    bool isStreamedOut() const { return !m_SDFBlocks.empty(); }
+    std::vector<SDFBlockDesc>& getSDFBlockDescs() { return m_ChunkDesc; }
+    std::vector<vh::SDFBlock>& getSDFBlocks() { return m_SDFBlocks; }
+    const std::vector<SDFBlockDesc>& getSDFBlockDescs() const { return m_ChunkDesc; }
+    const std::vector<vh::SDFBlock>& getSDFBlocks() const { return m_SDFBlocks; }
+
+private:
+    std::vector<vh::SDFBlock> m_SDFBlocks;
+    std::vector<SDFBlockDesc> m_ChunkDesc;
+};
+
+class CUDASceneRepChunkGrid {
+public:
+    // DSC/CUDASceneRepChunkGrid.h:155
+    CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSDF, const vh::vec3f& voxelExtends,
+                          const vh::vec3i& gridDimensions, const vh::vec3i& minGridPos,
+                          unsigned int initialChunkListSize, bool streamingEnabled, unsigned int streamOutParts);
+    ~CUDASceneRepChunkGrid();
+    CUDASceneRepChunkGrid(const CUDASceneRepChunkGrid&) = delete;
+    CUDASceneRepChunkGrid& operator=(const CUDASceneRepChunkGrid&) = delete;
+
+    // stream out (GPU -> host), DSC/CUDASceneRepChunkGrid.cpp:31-153
+    void streamOutToCPUAll();
+    void streamOutToCPU(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks);
+    void streamOutToCPUPass0GPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded = true);
+    void streamOutToCPUPass1CPU(bool multiThreaded = true);
+    void integrateInChunkGrid(const SDFBlockDesc* desc, const vh::SDFBlock* block, unsigned int nSDFBlocks);
+
+    // stream in (host -> GPU), DSC/CUDASceneRepChunkGrid.cpp:155-311
+    void streamInToGPUAll();
+    void streamInToGPUAll(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks);
+    void streamInToGPUChunk(const vh::vec3i& chunkPos);
+    void streamInToGPUChunkNeighborhood(const vh::vec3i& chunkPos, int kernelRadius);
+    void streamInToGPU(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks);
+    void streamInToGPUPass0CPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded = true);
+    void streamInToGPUPass1GPU(bool multiThreaded = true);
+    unsigned int integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts);
+
+    void debugCheckForDuplicates() const; // .cpp:313-341; throws vh::Error
+    void startMultiThreading();           // .h:248
+    void stopMultiThreading();            // .h:262
+    void clearGrid();                     // .h:291
+    void reset();                         // .h:297
+    // .h:306 -- uploads the bit mask only if it changed since the last call
+    unsigned int* getBitMaskGPU();
+    bool containsSDFBlocksChunk(const vh::vec3i& chunk) const;                               // .h:311
+    bool isChunkInSphere(const vh::vec3i& chunk, const vh::vec3f& center, float radius) const; // .h:317
+    bool containsSDFBlocksChunkInRadius(const vh::vec3i& chunk, int chunkRadius) const;      // .h:348
+
+    const vh::vec3i& getMinGridPos() const { return m_minGridPos; }
+    const vh::vec3i& getMaxGridPos() const { return m_maxGridPos; }
+    const vh::vec3f& getVoxelExtends() const { return m_voxelExtents; }
+    vh::vec3f getWorldPosChunk(const vh::vec3i& chunk) const { return chunkToWorld(chunk); }
+    void getStatistics(unsigned int out[3]) const; // chunks, blocks on host, bits set
+
+    // .hashgrid version 1, DSC/CUDASceneRepChunkGrid.h:456-548 (mLib BinaryDataStreamFile layout)
+    void saveToFile(const std::string& filename, const vh::vec3f& camPos, float radius);
+    void loadFromFile(const std::string& filename, const vh::vec3f& camPos, float radius);
+
+    const vh::vec3f& getPosCamera() const { return s_posCamera; }
+    float getRadius() const { return s_radius; }
+    bool getTerminatedThread() const { return s_terminateThread; }
+    static const bool s_useParts = true;
+
+    // host-side content (sorted by chunk index, insertion order inside a chunk)
+    void downloadHostBlocks(std::vector<SDFBlockDesc>& descs, std::vector<vh::SDFBlock>& blocks) const;
+
+    // helpers (private in the reference, .h:560-640)
+    bool isValidChunk(const vh::vec3i& chunk) const;
+    vh::vec3i worldToChunks(const vh::vec3f& posWorld) const;
+    vh::vec3f chunkToWorld(const vh::vec3i& posChunk) const;
+    vh::vec3i delinearizeChunkIndex(unsigned int idx) const;
+    unsigned int linearizeChunkPos(const vh::vec3i& chunkPos) const;
+    vh::vec3i meterToNumberOfChunksCeil(float f) const;
+    float getChunkRadiusInMeter() const;
+    float getGridRadiusInMeter() const;
+
+private:
+    struct AutoResetEvent { // Win32 auto-reset event (CreateEvent(NULL, FALSE, initial, NULL))
+        std::mutex mtx;
+        std::condition_variable cv;
+        bool signaled = false;
+        void set();
+        void wait();
+        void reset(bool state);
+    };
+    void workerLoop();
+    void create(const vh::vec3f& voxelExtends, const vh::vec3i& gridDimensions, const vh::vec3i& minGridPos,
+                unsigned int initialChunkListSize, bool streamingEnabled);
+    void destroy();
+    void setBit(unsigned int index);
+    void resetBit(unsigned int index);
+
+    unsigned int m_maxNumberOfSDFBlocksIntegrateFromGlobalHash;
+
+    SDFBlockDesc* h_SDFBlockDescOutput; // pinned
+    vh::SDFBlock* h_SDFBlockOutput;     // pinned
+    SDFBlockDesc* h_SDFBlockDescInput;  // pinned staging for the worker's H2D
+    vh::SDFBlock* h_SDFBlockInput;      // pinned
+    uint32_t* h_counter;                // pinned
+    SDFBlockDesc* d_SDFBlockDescOutput;
+    SDFBlockDesc* d_SDFBlockDescInput;
+    vh::SDFBlock* d_SDFBlockOutput;
+    vh::SDFBlock* d_SDFBlockInput;
+    unsigned int* d_SDFBlockCounter;
+    unsigned int* d_bitMask;
+    void* m_copyStream; // hipStream_t of the worker thread
+
+    vh::vec3f m_voxelExtents;
+    vh::vec3i m_gridDimensions;
+    vh::vec3i m_minGridPos;
+    vh::vec3i m_maxGridPos;
+    unsigned int m_initialChunkDescListSize;
+
+    std::unordered_map<unsigned int, std::unique_ptr<ChunkDesc>> m_grid; // sparse: chunk index -> chunk
+    std::vector<unsigned int> m_bitMask;                                 // BitArray<unsigned int>, DSC/BitArray.h
+    bool m_bitMaskDirty;
+    mutable std::mutex m_gridMutex;
+
+    unsigned int m_currentPart;
+    unsigned int m_streamOutParts;
+
+    std::thread m_thread;
+    std::mutex hMutexOut, hMutexIn;
+    AutoResetEvent hEventOutProduce, hEventOutConsume, hEventInProduce, hEventInConsume;
+
+    vh::vec3f s_posCamera;
+    float s_radius;
+    unsigned int s_nStreamdInBlocks;
+    unsigned int s_nStreamdOutBlocks;
+    volatile bool s_terminateThread;
+
+    CUDASceneRepHashSDF* m_sceneRepHashSDF;
+};
+
+#endif // VH_HPP

@@ -1,0 +1,213 @@
+/*
+ * vh_api.h -- C ABI of the MI355X voxel-hashing TSDF fusion + raycast engine.
+ *
+ * Drop-in boundary: the reference's host classes call `extern "C"` launchers
+ * defined in its .cu files (C++ references, by-value structs -- not C-ABI
+ * clean).  This header is their pointer-based twin; every entry point cites the
+ * reference interface it replaces.
+ *
+ *   DSC/ = /root/reference/DepthSensingCUDA/Source/
+ *
+ * Conventions
+ *  - all pointers inside VhHashData / VhDepthCameraData / VhRayCastData are
+ *    DEVICE pointers; parameter structs are host pointers, read at call time
+ *    and passed to the kernels as arguments (no __constant__ singletons, so
+ *    several scenes per process are possible);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *    launcher is asynchronous unless it documents a read-back;
+ *  - return value: 0 ok, <0 = -(hipError_t), >0 = VH_ERR_* (vh_types.h);
+ *  - `lockToken`: value written into d_hashBucketMutex to take a bucket for
+ *    the rest of the pass.  VH_LOCK_ENTRY reproduces the reference (caller
+ *    resets the mutex array before the pass with vh_reset_bucket_mutex); any
+ *    other value that differs from every token used since the last reset
+ *    makes that reset unnecessary (the host classes use a running epoch).
+ */
+#ifndef VH_API_H
+#define VH_API_H
+
+#include "vh_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vhStream_t;
+
+/* ---- library -------------------------------------------------------------- */
+const char* vh_version(void);
+const char* vh_error_string(int code);
+/* text of the last error raised by a handle-level call on this thread */
+const char* vh_last_error_message(void);
+
+/* ---- device memory helpers (thin hipMalloc/hipMemcpy wrappers for FFI users) */
+int vh_malloc(void** devPtr, size_t bytes);
+int vh_free(void* devPtr);
+int vh_memcpy_h2d(void* dst, const void* src, size_t bytes, vhStream_t stream);
+int vh_memcpy_d2h(void* dst, const void* src, size_t bytes, vhStream_t stream); /* synchronises the stream */
+int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream);
+int vh_stream_synchronize(vhStream_t stream);
+int vh_device_synchronize(void);
+
+/* ---- HashData ownership: HashData::allocate / free, DSC/VoxelUtilHashSDF.h:113-181 */
+int vh_hash_data_alloc(VhHashData* hd, const VhHashParams* hp);
+int vh_hash_data_free(VhHashData* hd);
+
+/* ---- scene-rep launchers: DSC/CUDASceneRepHashSDF.h:15-26 ------------------- */
+/* resetCUDA(HashData&, const HashParams&)                       DSC/CUDASceneRepHashSDF.cu:63 */
+int vh_reset(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream);
+/* resetHashBucketMutexCUDA(HashData&, const HashParams&)        DSC/CUDASceneRepHashSDF.cu:109 */
+int vh_reset_bucket_mutex(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream);
+/* allocCUDA(HashData&, const HashParams&, const DepthCameraData&, const DepthCameraParams&,
+ *           const unsigned int* d_bitMask)                      DSC/CUDASceneRepHashSDF.cu:245
+ * d_bitMask may be NULL (streaming disabled). */
+int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+             const VhDepthCameraParams* cp, const uint32_t* d_bitMask, int32_t lockToken, vhStream_t stream);
+/* unsigned compactifyHashAllInOneCUDA(HashData&, const HashParams&)  DSC/CUDASceneRepHashSDF.cu:361
+ * The count lands in d_hashCompactifiedCounter.  numOccupied != NULL: blocking
+ * read-back as the reference does; NULL: fully asynchronous. */
+int vh_compactify(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp,
+                  uint32_t* numOccupied, vhStream_t stream);
+/* integrateDepthMapCUDA(...)                                     DSC/CUDASceneRepHashSDF.cu:495
+ * integrates hp->m_numOccupiedBlocks compactified blocks. */
+int vh_integrate(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+                 const VhDepthCameraParams* cp, vhStream_t stream);
+/* starveVoxelsKernelCUDA(HashData&, const HashParams&)          DSC/CUDASceneRepHashSDF.cu:523 */
+int vh_starve(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream);
+/* garbageCollectIdentifyCUDA(HashData&, const HashParams&)      DSC/CUDASceneRepHashSDF.cu:592 */
+int vh_gc_identify(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, vhStream_t stream);
+/* garbageCollectFreeCUDA(HashData&, const HashParams&)          DSC/CUDASceneRepHashSDF.cu:631 */
+int vh_gc_free(const VhHashData* hd, const VhHashParams* hp, int32_t lockToken, vhStream_t stream);
+/* bindInputDepthColorTextures(const DepthCameraData&)           DSC/CUDASceneRepHashSDF.cu:15
+ * images are read with plain loads: kept as a no-op for source compatibility. */
+int vh_bind_input_depth_color_textures(const VhDepthCameraData* cam);
+
+/* Fused integrate -> [starve] -> GC identify -> GC free in ONE pass over the
+ * voxels (one read + one write per voxel instead of up to four kernels);
+ * same results as the four launchers above in the reference's order
+ * (CUDASceneRepHashSDF::integrateDepthMap + garbageCollect, DSC/CUDASceneRepHashSDF.h:317-339).
+ * The block count is read on the device from d_hashCompactifiedCounter. */
+enum { VH_FUSED_GC = 1, VH_FUSED_STARVE = 2 };
+int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, vhStream_t stream);
+
+/* ---- ray-cast launchers: DSC/CUDARayCastSDF.cpp:10-21 ----------------------- */
+/* renderCS(const HashData&, const RayCastData&, const DepthCameraData&, const RayCastParams&)
+ *                                                               DSC/CUDARayCastSDF.cu:59 */
+int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd,
+              const VhDepthCameraParams* cp, const VhRayCastParams* rp, vhStream_t stream);
+/* computeNormals(float4* d_output, float4* d_input, width, height)  DSC/CameraUtil.cu:699 */
+int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream);
+
+/* ---- streaming launchers: DSC/CUDASceneRepChunkGrid.h:142-146 --------------- */
+/* integrateFromGlobalHashPass1CUDA(params, hashData, threadsPerPart, start, radius, camPos,
+ *                                  d_outputCounter, d_output)   DSC/CUDASceneRepChunkGrid.cu:76 */
+int vh_stream_out_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start,
+                        float radius, const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_output,
+                        uint32_t outputCapacity, int32_t lockToken, vhStream_t stream);
+/* integrateFromGlobalHashPass2CUDA(params, hashData, threadsPerPart, descs, d_output, n)  :115 */
+int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSDFBlockDesc* d_descs,
+                        VhVoxel* d_output, uint32_t nSDFBlocks, vhStream_t stream);
+/* chunkToGlobalHashPass1CUDA(params, hashData, n, heapCountPrev, descs, blocks)           :162 */
+int vh_stream_in_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                       const VhSDFBlockDesc* d_descs, int32_t lockToken, vhStream_t stream);
+/* chunkToGlobalHashPass2CUDA(params, hashData, n, heapCountPrev, descs, blocks)           :192 */
+int vh_stream_in_pass2(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                       const VhSDFBlockDesc* d_descs, const VhVoxel* d_blocks, vhStream_t stream);
+
+/* ---- utilities that are not in the reference -------------------------------- */
+/* Synthetic analytic-sphere depth+colour frame,
+ * generated on the device so benchmark inputs are HBM-resident. */
+int vh_synth_frame(const double* h_spheres, int nSpheres, int inside, const float camToWorld[16],
+                   const VhDepthCameraParams* cp, float* d_depth, float* d_color4, vhStream_t stream);
+/* Executes a list of hash operations one after the other in a single thread:
+ * deterministic exercise of allocBlock / deleteHashEntryElement /
+ * insertHashEntry / getHashEntryForSDFBlockPos including collision lists.
+ * ops: n x {op, x, y, z, arg}; results: n ints.  op 0 = alloc, 1 = delete,
+ * 2 = insert(ptr = arg), 3 = lookup (result = ptr), 4 = new lock pass. */
+enum { VH_OP_ALLOC = 0, VH_OP_DELETE = 1, VH_OP_INSERT = 2, VH_OP_LOOKUP = 3, VH_OP_NEW_PASS = 4 };
+int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_t* d_ops, int32_t* d_results,
+                      uint32_t n, vhStream_t stream);
+
+/* ---- host classes (opaque handles over the C++ classes of include/vh.hpp) ---- */
+typedef struct VhSceneRep VhSceneRep;   /* CUDASceneRepHashSDF,   DSC/CUDASceneRepHashSDF.h:28 */
+typedef struct VhRayCast VhRayCast;     /* CUDARayCastSDF,        DSC/CUDARayCastSDF.h:13 */
+typedef struct VhChunkGrid VhChunkGrid; /* CUDASceneRepChunkGrid, DSC/CUDASceneRepChunkGrid.h:152 */
+
+/* CUDASceneRepHashSDF(const HashParams&) :31 ; the five GlobalAppState flags arrive as options */
+int vh_scene_rep_create(const VhHashParams* hp, const VhSceneOptions* opt, vhStream_t stream, VhSceneRep** out);
+void vh_scene_rep_destroy(VhSceneRep* s);
+/* integrate(lastRigidTransform, depthCameraData, depthCameraParams, d_bitMask) :64 */
+int vh_scene_rep_integrate(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraData* cam,
+                           const VhDepthCameraParams* cp, const uint32_t* d_bitMask);
+/* setLastRigidTransformAndCompactify :90 */
+int vh_scene_rep_set_last_rigid_transform_and_compactify(VhSceneRep* s, const float rigidTransform[16],
+                                                         const VhDepthCameraParams* cp);
+/* reset() :101 */
+int vh_scene_rep_reset(VhSceneRep* s);
+/* getHashData() :112 / getHashParams() :116 / getLastRigidTransform() :96 */
+int vh_scene_rep_get_hash_data(VhSceneRep* s, VhHashData* out);
+int vh_scene_rep_get_hash_params(VhSceneRep* s, VhHashParams* out);
+/* getHeapFreeCount() :122 (blocking read-back) */
+int vh_scene_rep_get_heap_free_count(VhSceneRep* s, uint32_t* out);
+/* blocking, exact count of in-frustum blocks of the last compactify */
+int vh_scene_rep_get_num_occupied_blocks(VhSceneRep* s, uint32_t* out);
+/* debugHash() :129-233: 0 if every invariant holds; report = {numOccupied, numFree, duplicates, lockEntries} */
+int vh_scene_rep_debug_hash(VhSceneRep* s, uint32_t report[4]);
+/* device-side status words (heap underflow, failed inserts, lost lock races): copies VH_STATE_WORDS words */
+int vh_scene_rep_get_state(VhSceneRep* s, uint32_t* out);
+/* per-stage device time in ms accumulated while s_timingsDetailledEnabled:
+ * {alloc, compactify, integrate(+gc), count} (TimingLog of the reference) */
+int vh_scene_rep_get_timings(VhSceneRep* s, double out[4]);
+int vh_scene_rep_set_options(VhSceneRep* s, const VhSceneOptions* opt);
+
+/* CUDARayCastSDF(const RayCastParams&) :16 */
+int vh_raycast_create(const VhRayCastParams* rp, vhStream_t stream, VhRayCast** out);
+void vh_raycast_destroy(VhRayCast* r);
+/* render(hashData, hashParams, cameraData, lastRigidTransform), DSC/CUDARayCastSDF.cpp:38 */
+int vh_raycast_render(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp,
+                      const VhDepthCameraParams* cp, const float lastRigidTransform[16]);
+/* getRayCastData() :42 / getRayCastParams() :45 */
+int vh_raycast_get_data(VhRayCast* r, VhRayCastData* out);
+int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out);
+/* device time in ms of render() accumulated while timing is enabled: {raycast, normals, count} */
+int vh_raycast_get_timings(VhRayCast* r, double out[3]);
+int vh_raycast_set_timing(VhRayCast* r, int enabled);
+
+/* CUDASceneRepChunkGrid(sceneRep, voxelExtends, gridDimensions, minGridPos, initialChunkListSize,
+ *                       streamingEnabled, streamOutParts)         DSC/CUDASceneRepChunkGrid.h:155 */
+int vh_chunk_grid_create(VhSceneRep* s, const float voxelExtents[3], const int32_t gridDimensions[3],
+                         const int32_t minGridPos[3], uint32_t initialChunkListSize, int streamingEnabled,
+                         uint32_t streamOutParts, VhChunkGrid** out);
+void vh_chunk_grid_destroy(VhChunkGrid* g);
+/* streamOutToCPUPass0GPU(posCamera, radius, useParts, multiThreaded)  DSC/CUDASceneRepChunkGrid.cpp:55 */
+int vh_chunk_grid_stream_out_to_cpu_pass0_gpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, int multiThreaded);
+/* streamOutToCPUPass1CPU(multiThreaded) :107 */
+int vh_chunk_grid_stream_out_to_cpu_pass1_cpu(VhChunkGrid* g, int multiThreaded);
+/* streamInToGPUPass0CPU(posCamera, radius, useParts, multiThreaded) :208 */
+int vh_chunk_grid_stream_in_to_gpu_pass0_cpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, int multiThreaded);
+/* streamInToGPUPass1GPU(multiThreaded) :227 */
+int vh_chunk_grid_stream_in_to_gpu_pass1_gpu(VhChunkGrid* g, int multiThreaded);
+/* streamOutToCPU / streamInToGPU (both passes, single-threaded) :44 / :197 ; nStreamedBlocks out */
+int vh_chunk_grid_stream_out_to_cpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, uint32_t* nStreamedBlocks);
+int vh_chunk_grid_stream_in_to_gpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, uint32_t* nStreamedBlocks);
+/* streamOutToCPUAll() :31 / streamInToGPUAll(posCamera, radius, useParts, n) :164 */
+int vh_chunk_grid_stream_out_to_cpu_all(VhChunkGrid* g);
+int vh_chunk_grid_stream_in_to_gpu_all(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, uint32_t* nStreamedBlocks);
+/* getBitMaskGPU() DSC/CUDASceneRepChunkGrid.h:306 (uploads only when the mask changed) */
+int vh_chunk_grid_get_bit_mask_gpu(VhChunkGrid* g, const uint32_t** d_bitMask);
+/* reset() :297 */
+int vh_chunk_grid_reset(VhChunkGrid* g);
+/* debugCheckForDuplicates() DSC/CUDASceneRepChunkGrid.cpp:313: 0 if no block is present twice */
+int vh_chunk_grid_debug_check_for_duplicates(VhChunkGrid* g);
+/* host-side statistics: {chunks allocated, blocks on the host, bits set} */
+int vh_chunk_grid_get_statistics(VhChunkGrid* g, uint32_t out[3]);
+/* copies the host chunk grid content: descs[n], blocks[n*512] (pass NULL to query n) */
+int vh_chunk_grid_download_host_blocks(VhChunkGrid* g, VhSDFBlockDesc* descs, VhVoxel* blocks, uint32_t capacity, uint32_t* n);
+/* saveToFile / loadFromFile (.hashgrid v1) DSC/CUDASceneRepChunkGrid.h:459-548 */
+int vh_chunk_grid_save_to_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
+int vh_chunk_grid_load_from_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VH_API_H */

@@ -1,0 +1,188 @@
+/*
+ * vh_types.h -- plain-old-data types of the voxel-hashing TSDF hot path.
+ *
+ * C-compatible (included by the HIP library, by the C oracle and by FFI users).
+ * Every struct names the reference type it replaces.  Field names and field
+ * order follow the reference so that a maintainer can memcpy between the two.
+ *
+ *   DSC/ = /root/reference/DepthSensingCUDA/Source/
+ */
+#ifndef VH_TYPES_H
+#define VH_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Compile-time constants of the reference (DSC/VoxelUtilHashSDF.h:39-54). */
+#define VH_SDF_BLOCK_SIZE 8
+#define VH_SDF_BLOCK_VOXELS 512 /* 8*8*8 */
+#define VH_HASH_BUCKET_SIZE 10
+#define VH_LOCK_ENTRY (-1)
+#define VH_FREE_ENTRY (-2)
+#define VH_NO_OFFSET 0
+
+/* HashEntry, DSC/VoxelUtilHashSDF.h:56-74.  20 B payload; 32 B stride is what
+ * __align__(16) yields on the reference toolchain and gives 16 B-aligned
+ * {pos,ptr} quads for single dwordx4 probes on gfx950. */
+typedef struct VhHashEntry {
+    int32_t pos[3];   /* SDF-block coordinates (x,y,z) */
+    int32_t ptr;      /* first voxel index (= block id * 512), or FREE/LOCK */
+    uint32_t offset;  /* collision-list hop, relative to the home bucket's last slot */
+    uint32_t _pad[3];
+} VhHashEntry;
+
+/* Voxel, DSC/VoxelUtilHashSDF.h:76-88.  8 B, moved as one 64-bit word. */
+typedef struct VhVoxel {
+    float sdf;
+    uint8_t color[3];
+    uint8_t weight;
+} VhVoxel;
+
+/* HashParams, DSC/CUDAHashParams.h:8-38 (224 B). Matrices are row-major
+ * (DSC/cuda_SimpleMatrixUtil.h:1127-1137: entries[16] = m11,m12,...,m44). */
+typedef struct VhHashParams {
+    float m_rigidTransform[16];
+    float m_rigidTransformInverse[16];
+
+    uint32_t m_hashNumBuckets;
+    uint32_t m_hashBucketSize;
+    uint32_t m_hashMaxCollisionLinkedListSize;
+    uint32_t m_numSDFBlocks;
+
+    int32_t m_SDFBlockSize;
+    float m_virtualVoxelSize;
+    uint32_t m_numOccupiedBlocks; /* occupied blocks in the viewing frustum */
+
+    float m_maxIntegrationDistance;
+    float m_truncScale;
+    float m_truncation;
+    uint32_t m_integrationWeightSample;
+    uint32_t m_integrationWeightMax;
+
+    float m_streamingVoxelExtents[3];
+    int32_t m_streamingGridDimensions[3];
+    int32_t m_streamingMinGridPos[3];
+    uint32_t m_streamingInitialChunkListSize;
+    uint32_t m_dummy[2];
+} VhHashParams;
+
+/* DepthCameraParams, DSC/CUDADepthCameraParams.h:8-19 (32 B). */
+typedef struct VhDepthCameraParams {
+    float fx, fy, mx, my;
+    uint32_t m_imageWidth;
+    uint32_t m_imageHeight;
+    float m_sensorDepthWorldMin;
+    float m_sensorDepthWorldMax;
+} VhDepthCameraParams;
+
+/* RayCastParams, DSC/CUDARayCastParams.h:7-28 (304 B). */
+typedef struct VhRayCastParams {
+    float m_viewMatrix[16];
+    float m_viewMatrixInverse[16];
+    float m_intrinsics[16];
+    float m_intrinsicsInverse[16];
+
+    uint32_t m_width;
+    uint32_t m_height;
+
+    uint32_t m_numOccupiedSDFBlocks;
+    uint32_t m_maxNumVertices;
+    int32_t m_splatMinimum;
+
+    float m_minDepth;
+    float m_maxDepth;
+    float m_rayIncrement;
+    float m_thresSampleDist;
+    float m_thresDist;
+    uint8_t m_useGradients; /* bool in the reference */
+    uint8_t _pad0[3];
+
+    uint32_t dummy0;
+} VhRayCastParams;
+
+/* HashData, DSC/VoxelUtilHashSDF.h:813-823: the nine device buffers, in the
+ * reference's order.  Two extension buffers follow (not in the reference):
+ * a per-bucket occupancy count and a 1-bit-per-bucket summary that let the
+ * compaction and the ray caster skip empty buckets without touching d_hash.
+ * They are owned by vh_hash_data_alloc()/vh_hash_data_free() like the rest. */
+typedef struct VhHashData {
+    uint32_t* d_heap;                  /* [numSDFBlocks] free-list of block ids */
+    uint32_t* d_heapCounter;           /* [1] index of the top free element */
+    int32_t* d_hashDecision;           /* [numEntries] GC decisions (first No used) */
+    int32_t* d_hashDecisionPrefix;     /* [numEntries] kept for layout parity; unused */
+    VhHashEntry* d_hash;               /* [numEntries] */
+    VhHashEntry* d_hashCompactified;   /* [numEntries] in-frustum occupied entries */
+    int32_t* d_hashCompactifiedCounter;/* [1] */
+    VhVoxel* d_SDFBlocks;              /* [numSDFBlocks*512] */
+    int32_t* d_hashBucketMutex;        /* [numBuckets] */
+    uint8_t m_bIsOnGPU;
+    uint8_t _pad0[7];
+    /* --- extensions --- */
+    uint32_t* d_bucketCount;           /* [numBuckets] occupied slots physically in bucket */
+    uint32_t* d_bucketBits;            /* [ceil(numBuckets/32)] bit b = (d_bucketCount[b] != 0) */
+    uint32_t* d_state;                 /* [VH_STATE_WORDS] device-side status words */
+} VhHashData;
+
+/* words of VhHashData::d_state */
+enum {
+    VH_STATE_HEAP_UNDERFLOW = 0, /* consumeHeap found the heap empty */
+    VH_STATE_INSERT_FAILED = 1,  /* stream-in: insertHashEntry returned false */
+    VH_STATE_ALLOC_LOCK_LOST = 2,/* alloc requests that lost a bucket lock this pass */
+    VH_STATE_WORDS = 16
+};
+
+/* DepthCameraData, DSC/DepthCameraUtil.h:17-159: the two image buffers the
+ * path reads (the cudaArray/texture twins of the reference are not needed:
+ * images are read with plain cached loads). */
+typedef struct VhDepthCameraData {
+    const float* d_depthData; /* [H*W] metres; invalid = -inf (MINF) or 0 */
+    const float* d_colorData; /* [H*W*4] float4 rgba in [0,1]; invalid = MINF in .x; may be NULL */
+} VhDepthCameraData;
+
+/* RayCastData, DSC/RayCastSDFUtil.h:266-274: the four output maps. */
+typedef struct VhRayCastData {
+    float* d_depth;   /* [H*W]   */
+    float* d_depth4;  /* [H*W*4] camera-space position, w=1 */
+    float* d_normals; /* [H*W*4] */
+    float* d_colors;  /* [H*W*4] */
+} VhRayCastData;
+
+/* SDFBlockDesc, DSC/CUDASceneRepChunkGrid.cu:13-16 / .h:24-51 (16 B):
+ * streaming wire/disk unit, together with a 4096 B block of 512 voxels. */
+typedef struct VhSDFBlockDesc {
+    int32_t pos[3];
+    int32_t ptr;
+} VhSDFBlockDesc;
+
+/* The five GlobalAppState flags the reference host classes read
+ * (DSC/CUDASceneRepHashSDF.h:249,251,329,331; DSC/CUDASceneRepChunkGrid.cpp:13). */
+typedef struct VhSceneOptions {
+    uint8_t s_offlineProcessing;        /* alloc until fixed point (host loop) */
+    uint8_t s_garbageCollectionEnabled;
+    uint8_t s_timingsDetailledEnabled;  /* record per-stage HIP events */
+    uint8_t s_useReferenceLaunchSequence; /* not in the reference: 1 = run integrate / starve / identify /
+                                             mutex reset / free as separate launches with host-side counts
+                                             (the reference's sequence) instead of the fused kernel */
+    uint32_t s_garbageCollectionStarve; /* starve every n-th frame */
+    uint32_t s_streamingOutParts;
+} VhSceneOptions;
+
+/* Error codes of the C ABI: 0 ok; <0 = -(hipError_t); >0 logical. */
+enum {
+    VH_OK = 0,
+    VH_ERR_HEAP_EXHAUSTED = 1,
+    VH_ERR_STAGING_OVERFLOW = 2,
+    VH_ERR_INSERT_FAILED = 3,
+    VH_ERR_BAD_ARGUMENT = 4,
+    VH_ERR_VERSION_MISMATCH = 5,
+    VH_ERR_IO = 6
+};
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* VH_TYPES_H */

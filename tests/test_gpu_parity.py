@@ -1,0 +1,93 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+identical synthetic inputs.  Integer / index results must be bit-exact on the
+canonical forms (voxelhashing_amd.canonical); float results (sdf, depth,
+normals) are compared BIT-EXACT as well -- tolerance 0, tighter than the 1e-4
+relative the north star allows -- because both sides are IEEE fp32 with the
+same operation order.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_maps_equal, bits, small_config
+from voxelhashing_amd import canonical, synth, vhtypes as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E(vh):
+    from voxelhashing_amd import engine
+    return engine
+
+
+def run_pair(E, O, hp, cp, rp, opt, poses, spheres, inside=0, render=True, check_each=True):
+    """drive the GPU engine and the oracle through the reference frame loop
+    (render with the previous pose, then integrate) and compare after every frame"""
+    g_scene = E.CUDASceneRepHashSDF(hp, opt)
+    g_ray = E.CUDARayCastSDF(rp)
+    o_scene = O.OracleScene(hp, cp, rp, opt)
+    frame = E.DepthFrame(cp)
+    last = None
+    for k, pose in enumerate(poses):
+        E.synth_frame(spheres, inside, pose, cp, out=frame)
+        depth, color = O.synth_frame(spheres, inside, pose, cp)
+        gd, gc = frame.download()
+        assert np.array_equal(bits(gd), bits(depth)), f"frame {k}: synthetic depth differs"
+        assert np.array_equal(bits(gc), bits(color)), f"frame {k}: synthetic colour differs"
+        if render and last is not None:
+            g_ray.render(g_scene.getHashData(), g_scene.getHashParams(), cp, last)
+            want = o_scene.render(last)
+            assert_maps_equal(g_ray.download(), want, f"frame {k} raycast")
+        g_scene.integrate(pose, frame, cp, None)
+        o_scene.integrate(pose, depth, color)
+        last = pose
+        if check_each or k == len(poses) - 1:
+            gs, os_ = g_scene.state(), o_scene.state()
+            canonical.assert_same_scene(gs, os_, f"frame {k}")
+            assert np.array_equal(canonical.compactified_set(gs["compactified"]), canonical.compactified_set(o_scene.compactified())), f"frame {k}: compactified sets differ"
+            assert g_scene.getNumOccupiedBlocks() == o_scene.hp.m_numOccupiedBlocks
+    return g_scene, g_ray, o_scene
+
+
+def test_synth_frame_matches_oracle(E, oracle_lib):
+    hp, cp, rp = small_config(200, 150)
+    for k in (0, 37, 250, 611):
+        pose = synth.orbit_pose(k)
+        fr = E.synth_frame(synth.S1_SPHERES, 0, pose, cp)
+        gd, gc = fr.download()
+        d, c = oracle_lib.synth_frame(synth.S1_SPHERES, 0, pose, cp)
+        assert np.array_equal(bits(gd), bits(d)) and np.array_equal(bits(gc), bits(c))
+        assert (d != -np.inf).sum() > 1000
+    pose = synth.orbit_pose(3, radius=synth.S2_ORBIT_RADIUS)
+    fr = E.synth_frame(synth.S2_SPHERES, 1, pose, cp)
+    gd, gc = fr.download()
+    d, c = oracle_lib.synth_frame(synth.S2_SPHERES, 1, pose, cp)
+    assert np.array_equal(bits(gd), bits(d)) and np.array_equal(bits(gc), bits(c))
+    assert (d != -np.inf).all()
+
+
+def test_single_frame_sphere(E, oracle_lib):
+    hp, cp, rp = small_config(160, 120)
+    opt = T.make_scene_options(offline=True, gc=False)
+    g, r, o = run_pair(E, oracle_lib, hp, cp, rp, opt, [synth.orbit_pose(0)], synth.SPHERE_A)
+    assert g.state()["num_occupied"] > 50
+    # raycast the integrated frame from the same pose
+    pose = synth.orbit_pose(0)
+    r.render(g.getHashData(), g.getHashParams(), cp, pose)
+    want = o.render(pose)
+    got = r.download()
+    assert_maps_equal(got, want, "raycast")
+    assert (got["depth"] != -np.inf).sum() > 1000
+    assert g.debugHash()["duplicates"] == 0
+
+
+@pytest.mark.parametrize("reference_sequence", [False, True])
+def test_orbit_gc_sequence(E, oracle_lib, reference_sequence):
+    """20 frames of S1 with GC + starve (starve=5 so it triggers): fused kernel
+    and the reference launch sequence both equal the oracle frame by frame"""
+    hp, cp, rp = small_config(96, 72)
+    opt = T.make_scene_options(offline=True, gc=True, starve=5, reference_launch_sequence=reference_sequence)
+    poses = [synth.orbit_pose(k, n_frames=200) for k in range(20)]
+    g, r, o = run_pair(E, oracle_lib, hp, cp, rp, opt, poses, synth.S1_SPHERES)
+    st = g.getState()
+    assert st[T.STATE_HEAP_UNDERFLOW] == 0 and st[T.STATE_INSERT_FAILED] == 0

@@ -1,0 +1,69 @@
+"""Builds libvoxelhashing_amd.so (HIP kernels + C ABI + host classes) in-tree
+for gfx950 with hipcc.  No GPU is needed to build.
+
+Flags that are part of the numerical contract (DESIGN.md "Numerics"):
+  -ffp-contract=off   no FMA contraction: block ids / pixel ids are float->int cliffs
+  -fhip-fp32-correctly-rounded-divide-sqrt   IEEE fp32 division and sqrt
+  (no -ffast-math)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvoxelhashing_amd.so")
+SOURCES = ["vh_kernels.hip", "vh_host.cpp", "vh_chunk_grid.cpp", "vh_c_api.cpp"]
+HEADERS = ["vh_device.hpp", "vh_host_util.hpp", "vh_stage_timer.hpp",
+           os.path.join(ROOT, "include", "vh_types.h"), os.path.join(ROOT, "include", "vh_api.h"),
+           os.path.join(ROOT, "include", "vh.hpp")]
+ARCH = "gfx950"
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def flags():
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+            "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
+            "-I", os.path.join(ROOT, "include")]
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps.append(os.path.abspath(__file__))
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and up_to_date():
+        return LIB
+    cc = hipcc()
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        cmd = [cc] + flags() + list(extra) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

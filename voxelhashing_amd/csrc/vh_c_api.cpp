@@ -1,0 +1,280 @@
+// vh_c_api.cpp -- handle-level C ABI over the C++ host classes (include/vh.hpp):
+// what an FFI binding (ctypes, cgo, JNI ...) of the reference's host-class
+// interface would call.  Exceptions become error codes here.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "../../include/vh.hpp"
+
+struct VhSceneRep { CUDASceneRepHashSDF impl; VhSceneRep(const HashParams& p, const VhSceneOptions& o, vhStream_t s) : impl(p, o, s) {} };
+struct VhRayCast { CUDARayCastSDF impl; VhRayCast(const RayCastParams& p, vhStream_t s) : impl(p, s) {} };
+struct VhChunkGrid {
+    CUDASceneRepChunkGrid impl;
+    VhChunkGrid(CUDASceneRepHashSDF* s, const vh::vec3f& e, const vh::vec3i& d, const vh::vec3i& m, unsigned int l, bool en, unsigned int parts)
+        : impl(s, e, d, m, l, en, parts) {}
+};
+
+namespace {
+
+thread_local char g_lastError[512] = "";
+
+template <class F> int guarded(F&& f)
+{
+    try {
+        f();
+        return VH_OK;
+    } catch (const vh::Error& e) {
+        std::strncpy(g_lastError, e.what(), sizeof(g_lastError) - 1);
+        return e.code ? e.code : VH_ERR_BAD_ARGUMENT;
+    } catch (const std::bad_alloc&) {
+        std::strncpy(g_lastError, "out of host memory", sizeof(g_lastError) - 1);
+        return -(int)hipErrorOutOfMemory;
+    } catch (const std::exception& e) {
+        std::strncpy(g_lastError, e.what(), sizeof(g_lastError) - 1);
+        return VH_ERR_BAD_ARGUMENT;
+    }
+}
+
+inline vh::mat4f toMat(const float m[16])
+{
+    vh::mat4f r;
+    std::memcpy(r.m, m, sizeof(r.m));
+    return r;
+}
+inline vh::vec3f toVec(const float v[3]) { return { v[0], v[1], v[2] }; }
+
+} // namespace
+
+extern "C" {
+
+const char* vh_last_error_message(void) { return g_lastError; }
+
+// ---- CUDASceneRepHashSDF ----------------------------------------------------
+
+int vh_scene_rep_create(const VhHashParams* hp, const VhSceneOptions* opt, vhStream_t stream, VhSceneRep** out)
+{
+    if (!hp || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] {
+        const VhSceneOptions o = opt ? *opt : CUDASceneRepHashSDF::defaultOptions();
+        *out = new VhSceneRep(*hp, o, stream);
+    });
+}
+void vh_scene_rep_destroy(VhSceneRep* s) { delete s; }
+
+int vh_scene_rep_integrate(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraData* cam,
+                           const VhDepthCameraParams* cp, const uint32_t* d_bitMask)
+{
+    if (!s || !rigidTransform || !cam || !cp) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.integrate(toMat(rigidTransform), *cam, *cp, d_bitMask); });
+}
+int vh_scene_rep_set_last_rigid_transform_and_compactify(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraParams* cp)
+{
+    if (!s || !rigidTransform || !cp) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.setLastRigidTransformAndCompactify(toMat(rigidTransform), *cp); });
+}
+int vh_scene_rep_reset(VhSceneRep* s)
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.reset(); });
+}
+int vh_scene_rep_get_hash_data(VhSceneRep* s, VhHashData* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = s->impl.getHashData();
+    return VH_OK;
+}
+int vh_scene_rep_get_hash_params(VhSceneRep* s, VhHashParams* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { *out = s->impl.getHashParams(); });
+}
+int vh_scene_rep_get_heap_free_count(VhSceneRep* s, uint32_t* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { *out = s->impl.getHeapFreeCount(); });
+}
+int vh_scene_rep_get_num_occupied_blocks(VhSceneRep* s, uint32_t* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { *out = s->impl.getNumOccupiedBlocks(); });
+}
+int vh_scene_rep_debug_hash(VhSceneRep* s, uint32_t report[4])
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.debugHash(report); });
+}
+int vh_scene_rep_get_state(VhSceneRep* s, uint32_t* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.getState(out); });
+}
+int vh_scene_rep_get_timings(VhSceneRep* s, double out[4])
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.getTimings(out); });
+}
+int vh_scene_rep_set_options(VhSceneRep* s, const VhSceneOptions* opt)
+{
+    if (!s || !opt) return VH_ERR_BAD_ARGUMENT;
+    s->impl.setOptions(*opt);
+    return VH_OK;
+}
+
+// ---- CUDARayCastSDF -----------------------------------------------------------
+
+int vh_raycast_create(const VhRayCastParams* rp, vhStream_t stream, VhRayCast** out)
+{
+    if (!rp || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] { *out = new VhRayCast(*rp, stream); });
+}
+void vh_raycast_destroy(VhRayCast* r) { delete r; }
+int vh_raycast_render(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp,
+                      const float lastRigidTransform[16])
+{
+    if (!r || !hd || !hp || !cp || !lastRigidTransform) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.render(*hd, *hp, *cp, toMat(lastRigidTransform)); });
+}
+int vh_raycast_get_data(VhRayCast* r, VhRayCastData* out)
+{
+    if (!r || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = r->impl.getRayCastData();
+    return VH_OK;
+}
+int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out)
+{
+    if (!r || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = r->impl.getRayCastParams();
+    return VH_OK;
+}
+int vh_raycast_get_timings(VhRayCast* r, double out[3])
+{
+    if (!r || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.getTimings(out); });
+}
+int vh_raycast_set_timing(VhRayCast* r, int enabled)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.setTiming(enabled != 0); });
+}
+
+// ---- CUDASceneRepChunkGrid ----------------------------------------------------
+
+int vh_chunk_grid_create(VhSceneRep* s, const float voxelExtents[3], const int32_t gridDimensions[3],
+                         const int32_t minGridPos[3], uint32_t initialChunkListSize, int streamingEnabled,
+                         uint32_t streamOutParts, VhChunkGrid** out)
+{
+    if (!s || !voxelExtents || !gridDimensions || !minGridPos || !out) return VH_ERR_BAD_ARGUMENT;
+    if (gridDimensions[0] <= 0 || gridDimensions[1] <= 0 || gridDimensions[2] <= 0) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] {
+        *out = new VhChunkGrid(&s->impl, toVec(voxelExtents), { gridDimensions[0], gridDimensions[1], gridDimensions[2] },
+                               { minGridPos[0], minGridPos[1], minGridPos[2] }, initialChunkListSize, streamingEnabled != 0, streamOutParts);
+    });
+}
+void vh_chunk_grid_destroy(VhChunkGrid* g) { delete g; }
+
+int vh_chunk_grid_stream_out_to_cpu_pass0_gpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, int multiThreaded)
+{
+    if (!g || !posCamera) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.streamOutToCPUPass0GPU(toVec(posCamera), radius, useParts != 0, multiThreaded != 0); });
+}
+int vh_chunk_grid_stream_out_to_cpu_pass1_cpu(VhChunkGrid* g, int multiThreaded)
+{
+    if (!g) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.streamOutToCPUPass1CPU(multiThreaded != 0); });
+}
+int vh_chunk_grid_stream_in_to_gpu_pass0_cpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, int multiThreaded)
+{
+    if (!g || !posCamera) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.streamInToGPUPass0CPU(toVec(posCamera), radius, useParts != 0, multiThreaded != 0); });
+}
+int vh_chunk_grid_stream_in_to_gpu_pass1_gpu(VhChunkGrid* g, int multiThreaded)
+{
+    if (!g) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.streamInToGPUPass1GPU(multiThreaded != 0); });
+}
+int vh_chunk_grid_stream_out_to_cpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, uint32_t* nStreamedBlocks)
+{
+    if (!g || !posCamera) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        unsigned int n = 0;
+        g->impl.streamOutToCPU(toVec(posCamera), radius, useParts != 0, n);
+        if (nStreamedBlocks) *nStreamedBlocks = n;
+    });
+}
+int vh_chunk_grid_stream_in_to_gpu(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, uint32_t* nStreamedBlocks)
+{
+    if (!g || !posCamera) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        unsigned int n = 0;
+        g->impl.streamInToGPU(toVec(posCamera), radius, useParts != 0, n);
+        if (nStreamedBlocks) *nStreamedBlocks = n;
+    });
+}
+int vh_chunk_grid_stream_out_to_cpu_all(VhChunkGrid* g)
+{
+    if (!g) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.streamOutToCPUAll(); });
+}
+int vh_chunk_grid_stream_in_to_gpu_all(VhChunkGrid* g, const float posCamera[3], float radius, int useParts, uint32_t* nStreamedBlocks)
+{
+    if (!g || !posCamera) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        unsigned int n = 0;
+        g->impl.streamInToGPUAll(toVec(posCamera), radius, useParts != 0, n);
+        if (nStreamedBlocks) *nStreamedBlocks = n;
+    });
+}
+int vh_chunk_grid_get_bit_mask_gpu(VhChunkGrid* g, const uint32_t** d_bitMask)
+{
+    if (!g || !d_bitMask) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { *d_bitMask = g->impl.getBitMaskGPU(); });
+}
+int vh_chunk_grid_reset(VhChunkGrid* g)
+{
+    if (!g) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.reset(); });
+}
+int vh_chunk_grid_debug_check_for_duplicates(VhChunkGrid* g)
+{
+    if (!g) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.debugCheckForDuplicates(); });
+}
+int vh_chunk_grid_get_statistics(VhChunkGrid* g, uint32_t out[3])
+{
+    if (!g || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.getStatistics(out); });
+}
+int vh_chunk_grid_download_host_blocks(VhChunkGrid* g, VhSDFBlockDesc* descs, VhVoxel* blocks, uint32_t capacity, uint32_t* n)
+{
+    if (!g || !n) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        std::vector<SDFBlockDesc> d;
+        std::vector<vh::SDFBlock> b;
+        g->impl.downloadHostBlocks(d, b);
+        *n = (uint32_t)d.size();
+        if (descs && blocks) {
+            if (d.size() > capacity) throw vh::Error(VH_ERR_STAGING_OVERFLOW, "download buffer too small");
+            if (!d.empty()) {
+                std::memcpy(descs, d.data(), sizeof(SDFBlockDesc) * d.size());
+                std::memcpy(blocks, b.data(), sizeof(vh::SDFBlock) * b.size());
+            }
+        }
+    });
+}
+int vh_chunk_grid_save_to_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius)
+{
+    if (!g || !filename || !camPos) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.saveToFile(filename, toVec(camPos), radius); });
+}
+int vh_chunk_grid_load_from_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius)
+{
+    if (!g || !filename || !camPos) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { g->impl.loadFromFile(filename, toVec(camPos), radius); });
+}
+
+} // extern "C"

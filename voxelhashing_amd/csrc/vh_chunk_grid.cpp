@@ -1,0 +1,724 @@
+// vh_chunk_grid.cpp -- CUDASceneRepChunkGrid: GPU <-> host streaming of SDF
+// blocks that leave / enter a sphere around the camera, the host chunk grid,
+// its bit mask and the .hashgrid file format.
+//
+// Behavioural contract: DSC/CUDASceneRepChunkGrid.{h,cpp}, DSC/BitArray.h
+// (DSC/ = /root/reference/DepthSensingCUDA/Source/).  Re-designed host side:
+//   - std::thread + condition variables replace the Win32 thread/event pairs;
+//   - the chunk grid is a sparse map (the reference keeps 257^3 pointers);
+//   - the worker's host->device copies run on their own HIP stream from
+//     pinned staging; the bit mask is uploaded only when it changed (the
+//     reference re-uploads all of it every frame, DSC/CUDASceneRepChunkGrid.h:306-309);
+//   - bucket locks use the scene's lock epoch instead of a mutex-array reset.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <unordered_set>
+
+#include "../../include/vh.hpp"
+#include "vh_host_util.hpp"
+
+namespace {
+
+inline void check(int code, const char* what)
+{
+    if (code != 0) throw vh::Error(code, std::string(what) + ": " + vh_error_string(code));
+}
+inline void checkHip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw vh::Error(-(int)e, std::string(what) + ": " + hipGetErrorString(e));
+}
+inline int signi(float v) { return (0.0f < v) - (v < 0.0f); }
+inline float length3(float x, float y, float z) { return std::sqrt(x * x + y * y + z * z); }
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// events
+// ---------------------------------------------------------------------------
+
+void CUDASceneRepChunkGrid::AutoResetEvent::set()
+{
+    {
+        std::lock_guard<std::mutex> l(mtx);
+        signaled = true;
+    }
+    cv.notify_one();
+}
+void CUDASceneRepChunkGrid::AutoResetEvent::wait()
+{
+    std::unique_lock<std::mutex> l(mtx);
+    cv.wait(l, [this] { return signaled; });
+    signaled = false;
+}
+void CUDASceneRepChunkGrid::AutoResetEvent::reset(bool state)
+{
+    std::lock_guard<std::mutex> l(mtx);
+    signaled = state;
+}
+
+// ---------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------
+
+CUDASceneRepChunkGrid::CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSDF, const vh::vec3f& voxelExtends,
+                                             const vh::vec3i& gridDimensions, const vh::vec3i& minGridPos,
+                                             unsigned int initialChunkListSize, bool streamingEnabled,
+                                             unsigned int streamOutParts)
+{
+    m_sceneRepHashSDF = sceneRepHashSDF;
+    m_currentPart = 0;
+    m_streamOutParts = streamOutParts ? streamOutParts : 1;
+    m_maxNumberOfSDFBlocksIntegrateFromGlobalHash = 100000; // DSC/CUDASceneRepChunkGrid.h:162
+    h_SDFBlockDescOutput = nullptr; h_SDFBlockOutput = nullptr;
+    h_SDFBlockDescInput = nullptr; h_SDFBlockInput = nullptr; h_counter = nullptr;
+    d_SDFBlockDescOutput = nullptr; d_SDFBlockDescInput = nullptr;
+    d_SDFBlockOutput = nullptr; d_SDFBlockInput = nullptr;
+    d_SDFBlockCounter = nullptr; d_bitMask = nullptr; m_copyStream = nullptr;
+    s_terminateThread = true; // by default the thread is disabled
+    s_nStreamdInBlocks = 0; s_nStreamdOutBlocks = 0;
+    s_posCamera = { 0.0f, 0.0f, 0.0f };
+    s_radius = 0.0f;
+    m_bitMaskDirty = true;
+    create(voxelExtends, gridDimensions, minGridPos, initialChunkListSize, streamingEnabled);
+}
+
+CUDASceneRepChunkGrid::~CUDASceneRepChunkGrid() { destroy(); }
+
+// DSC/CUDASceneRepChunkGrid.h:366-393
+void CUDASceneRepChunkGrid::create(const vh::vec3f& voxelExtends, const vh::vec3i& gridDimensions, const vh::vec3i& minGridPos,
+                                   unsigned int initialChunkListSize, bool streamingEnabled)
+{
+    m_voxelExtents = voxelExtends;
+    m_gridDimensions = gridDimensions;
+    m_initialChunkDescListSize = initialChunkListSize;
+    m_minGridPos = minGridPos;
+    m_maxGridPos = { minGridPos.x + gridDimensions.x, minGridPos.y + gridDimensions.y, minGridPos.z + gridDimensions.z };
+
+    const size_t nBits = (size_t)gridDimensions.x * gridDimensions.y * gridDimensions.z;
+    m_bitMask.assign((nBits + 31) / 32, 0u);
+
+    const size_t n = m_maxNumberOfSDFBlocksIntegrateFromGlobalHash;
+    checkHip(hipHostMalloc((void**)&h_SDFBlockDescOutput, sizeof(SDFBlockDesc) * n, hipHostMallocDefault), "hipHostMalloc");
+    checkHip(hipHostMalloc((void**)&h_SDFBlockOutput, sizeof(vh::SDFBlock) * n, hipHostMallocDefault), "hipHostMalloc");
+    checkHip(hipHostMalloc((void**)&h_SDFBlockDescInput, sizeof(SDFBlockDesc) * n, hipHostMallocDefault), "hipHostMalloc");
+    checkHip(hipHostMalloc((void**)&h_SDFBlockInput, sizeof(vh::SDFBlock) * n, hipHostMallocDefault), "hipHostMalloc");
+    checkHip(hipHostMalloc((void**)&h_counter, sizeof(uint32_t) * 2, hipHostMallocDefault), "hipHostMalloc");
+    checkHip(hipMalloc((void**)&d_SDFBlockDescOutput, sizeof(SDFBlockDesc) * n), "hipMalloc");
+    checkHip(hipMalloc((void**)&d_SDFBlockDescInput, sizeof(SDFBlockDesc) * n), "hipMalloc");
+    checkHip(hipMalloc((void**)&d_SDFBlockOutput, sizeof(vh::SDFBlock) * n), "hipMalloc");
+    checkHip(hipMalloc((void**)&d_SDFBlockInput, sizeof(vh::SDFBlock) * n), "hipMalloc");
+    checkHip(hipMalloc((void**)&d_SDFBlockCounter, sizeof(unsigned int)), "hipMalloc");
+    checkHip(hipMalloc((void**)&d_bitMask, sizeof(unsigned int) * m_bitMask.size()), "hipMalloc");
+    hipStream_t cs;
+    checkHip(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
+    m_copyStream = cs;
+
+    if (streamingEnabled) startMultiThreading();
+}
+
+void CUDASceneRepChunkGrid::destroy()
+{
+    stopMultiThreading();
+    clearGrid();
+    if (m_sceneRepHashSDF) (void)hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream());
+    if (m_copyStream) { (void)hipStreamSynchronize((hipStream_t)m_copyStream); (void)hipStreamDestroy((hipStream_t)m_copyStream); }
+    (void)hipHostFree(h_SDFBlockDescOutput); (void)hipHostFree(h_SDFBlockOutput);
+    (void)hipHostFree(h_SDFBlockDescInput); (void)hipHostFree(h_SDFBlockInput); (void)hipHostFree(h_counter);
+    (void)hipFree(d_SDFBlockDescOutput); (void)hipFree(d_SDFBlockDescInput);
+    (void)hipFree(d_SDFBlockOutput); (void)hipFree(d_SDFBlockInput);
+    (void)hipFree(d_SDFBlockCounter); (void)hipFree(d_bitMask);
+}
+
+// ---------------------------------------------------------------------------
+// worker thread (StreamingFunc, DSC/CUDASceneRepChunkGrid.cpp:8-29)
+// ---------------------------------------------------------------------------
+
+void CUDASceneRepChunkGrid::workerLoop()
+{
+    if (m_sceneRepHashSDF) {
+        // same device as the scene (one instance is bound to one device)
+    }
+    while (true) {
+        streamOutToCPUPass1CPU(true);
+        if (!m_sceneRepHashSDF->getOptions().s_offlineProcessing) {
+            // offline mode streams in from the main thread
+            try {
+                streamInToGPUPass0CPU(getPosCamera(), getRadius(), s_useParts, true);
+            } catch (const vh::Error&) {
+                // staging overflow: surfaced to the main thread through s_nStreamdInBlocks = 0
+                s_nStreamdInBlocks = 0;
+                hEventInConsume.set();
+            }
+        }
+        if (getTerminatedThread()) return;
+    }
+}
+
+// DSC/CUDASceneRepChunkGrid.h:248-260 + initializeCriticalSection :617-629
+void CUDASceneRepChunkGrid::startMultiThreading()
+{
+    if (!s_terminateThread) return;
+    hEventOutProduce.reset(true);
+    hEventOutConsume.reset(false);
+    hEventInProduce.reset(true);
+    hEventInConsume.reset(false);
+    s_terminateThread = false;
+    m_thread = std::thread(&CUDASceneRepChunkGrid::workerLoop, this);
+}
+
+// DSC/CUDASceneRepChunkGrid.h:262-289
+void CUDASceneRepChunkGrid::stopMultiThreading()
+{
+    if (!s_terminateThread) {
+        s_terminateThread = true;
+        hEventOutProduce.set();
+        hEventOutConsume.set();
+        hEventInProduce.set();
+        hEventInConsume.set();
+        if (m_thread.joinable()) m_thread.join();
+    }
+}
+
+void CUDASceneRepChunkGrid::clearGrid()
+{
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    m_grid.clear();
+}
+
+// DSC/CUDASceneRepChunkGrid.h:297-304
+void CUDASceneRepChunkGrid::reset()
+{
+    const bool wasRunning = !s_terminateThread;
+    stopMultiThreading();
+    clearGrid();
+    {
+        std::lock_guard<std::mutex> l(m_gridMutex);
+        std::fill(m_bitMask.begin(), m_bitMask.end(), 0u);
+        m_bitMaskDirty = true;
+    }
+    m_currentPart = 0;
+    if (wasRunning) startMultiThreading();
+}
+
+// ---------------------------------------------------------------------------
+// helpers (DSC/CUDASceneRepChunkGrid.h:560-614)
+// ---------------------------------------------------------------------------
+
+bool CUDASceneRepChunkGrid::isValidChunk(const vh::vec3i& c) const
+{
+    // the reference accepts c == maxGridPos (one past the last chunk), which indexes
+    // outside its grid; here a chunk is valid iff it lies inside the grid
+    if (c.x < m_minGridPos.x || c.y < m_minGridPos.y || c.z < m_minGridPos.z) return false;
+    if (c.x >= m_maxGridPos.x || c.y >= m_maxGridPos.y || c.z >= m_maxGridPos.z) return false;
+    return true;
+}
+
+vh::vec3i CUDASceneRepChunkGrid::worldToChunks(const vh::vec3f& posWorld) const
+{
+    const float px = posWorld.x / m_voxelExtents.x, py = posWorld.y / m_voxelExtents.y, pz = posWorld.z / m_voxelExtents.z;
+    vh::vec3i r;
+    r.x = (int)(px + (float)signi(px) * 0.5f);
+    r.y = (int)(py + (float)signi(py) * 0.5f);
+    r.z = (int)(pz + (float)signi(pz) * 0.5f);
+    return r;
+}
+
+vh::vec3f CUDASceneRepChunkGrid::chunkToWorld(const vh::vec3i& c) const
+{
+    return { (float)c.x * m_voxelExtents.x, (float)c.y * m_voxelExtents.y, (float)c.z * m_voxelExtents.z };
+}
+
+vh::vec3i CUDASceneRepChunkGrid::delinearizeChunkIndex(unsigned int idx) const
+{
+    const unsigned int x = idx % (unsigned int)m_gridDimensions.x;
+    const unsigned int y = (idx % (unsigned int)(m_gridDimensions.x * m_gridDimensions.y)) / (unsigned int)m_gridDimensions.x;
+    const unsigned int z = idx / (unsigned int)(m_gridDimensions.x * m_gridDimensions.y);
+    return { m_minGridPos.x + (int)x, m_minGridPos.y + (int)y, m_minGridPos.z + (int)z };
+}
+
+unsigned int CUDASceneRepChunkGrid::linearizeChunkPos(const vh::vec3i& c) const
+{
+    const unsigned int px = (unsigned int)(c.x - m_minGridPos.x), py = (unsigned int)(c.y - m_minGridPos.y), pz = (unsigned int)(c.z - m_minGridPos.z);
+    return pz * (unsigned int)m_gridDimensions.x * (unsigned int)m_gridDimensions.y + py * (unsigned int)m_gridDimensions.x + px;
+}
+
+vh::vec3i CUDASceneRepChunkGrid::meterToNumberOfChunksCeil(float f) const
+{
+    return { (int)std::ceil(f / m_voxelExtents.x), (int)std::ceil(f / m_voxelExtents.y), (int)std::ceil(f / m_voxelExtents.z) };
+}
+
+float CUDASceneRepChunkGrid::getChunkRadiusInMeter() const
+{
+    return length3(m_voxelExtents.x, m_voxelExtents.y, m_voxelExtents.z) / 2.0f;
+}
+
+float CUDASceneRepChunkGrid::getGridRadiusInMeter() const
+{
+    const vh::vec3f a = chunkToWorld(m_minGridPos), b = chunkToWorld(m_maxGridPos);
+    const float hx = m_voxelExtents.x / 2.0f, hy = m_voxelExtents.y / 2.0f, hz = m_voxelExtents.z / 2.0f;
+    return length3((a.x - hx) - (b.x + hx), (a.y - hy) - (b.y + hy), (a.z - hz) - (b.z + hz)) / 2.0f;
+}
+
+// conservative test: the *entire* chunk is within the sphere, DSC/CUDASceneRepChunkGrid.h:317-346
+bool CUDASceneRepChunkGrid::isChunkInSphere(const vh::vec3i& chunk, const vh::vec3f& center, float radius) const
+{
+    const vh::vec3f posWorld = chunkToWorld(chunk);
+    const float chunkExt = std::max(std::max(m_voxelExtents.x, m_voxelExtents.y), m_voxelExtents.z);
+    const float chunkRadius = 0.5f * chunkExt * std::sqrt(3.0f);
+    const float l = length3(posWorld.x - center.x, posWorld.y - center.y, posWorld.z - center.z);
+    return l <= std::abs(radius - chunkRadius);
+}
+
+bool CUDASceneRepChunkGrid::containsSDFBlocksChunk(const vh::vec3i& chunk) const
+{
+    if (!isValidChunk(chunk)) return false;
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    auto it = m_grid.find(linearizeChunkPos(chunk));
+    return it != m_grid.end() && it->second->isStreamedOut();
+}
+
+bool CUDASceneRepChunkGrid::containsSDFBlocksChunkInRadius(const vh::vec3i& chunk, int r) const
+{
+    const vh::vec3i s = { std::max(chunk.x - r, m_minGridPos.x), std::max(chunk.y - r, m_minGridPos.y), std::max(chunk.z - r, m_minGridPos.z) };
+    const vh::vec3i e = { std::min(chunk.x + r, m_maxGridPos.x), std::min(chunk.y + r, m_maxGridPos.y), std::min(chunk.z + r, m_maxGridPos.z) };
+    for (int x = s.x; x <= e.x; x++)
+        for (int y = s.y; y <= e.y; y++)
+            for (int z = s.z; z <= e.z; z++)
+                if (containsSDFBlocksChunk({ x, y, z })) return true;
+    return false;
+}
+
+void CUDASceneRepChunkGrid::setBit(unsigned int index)
+{
+    m_bitMask[index / 32] |= (1u << (index % 32));
+    m_bitMaskDirty = true;
+}
+void CUDASceneRepChunkGrid::resetBit(unsigned int index)
+{
+    m_bitMask[index / 32] &= ~(1u << (index % 32));
+    m_bitMaskDirty = true;
+}
+
+// DSC/CUDASceneRepChunkGrid.h:306-309
+unsigned int* CUDASceneRepChunkGrid::getBitMaskGPU()
+{
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    if (m_bitMaskDirty) {
+        hipStream_t s = (hipStream_t)m_sceneRepHashSDF->getStream();
+        // pageable source: the copy is staged before the call returns, so the lock can be dropped afterwards
+        checkHip(hipMemcpyAsync(d_bitMask, m_bitMask.data(), sizeof(unsigned int) * m_bitMask.size(), hipMemcpyHostToDevice, s), "getBitMaskGPU");
+        m_bitMaskDirty = false;
+    }
+    return d_bitMask;
+}
+
+void CUDASceneRepChunkGrid::getStatistics(unsigned int out[3]) const
+{
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    unsigned int blocks = 0, chunks = 0;
+    for (auto& kv : m_grid) { chunks++; blocks += kv.second->getNElements(); }
+    unsigned int bits = 0;
+    for (unsigned int w : m_bitMask) bits += (unsigned int)__builtin_popcount(w);
+    out[0] = chunks; out[1] = blocks; out[2] = bits;
+}
+
+void CUDASceneRepChunkGrid::downloadHostBlocks(std::vector<SDFBlockDesc>& descs, std::vector<vh::SDFBlock>& blocks) const
+{
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    std::vector<unsigned int> keys;
+    for (auto& kv : m_grid) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    descs.clear(); blocks.clear();
+    for (unsigned int k : keys) {
+        const ChunkDesc& c = *m_grid.at(k);
+        descs.insert(descs.end(), c.getSDFBlockDescs().begin(), c.getSDFBlockDescs().end());
+        blocks.insert(blocks.end(), c.getSDFBlocks().begin(), c.getSDFBlocks().end());
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stream out: GPU -> host
+// ---------------------------------------------------------------------------
+
+// DSC/CUDASceneRepChunkGrid.cpp:31-42
+void CUDASceneRepChunkGrid::streamOutToCPUAll()
+{
+    unsigned int nStreamedBlocksSum = 1;
+    while (nStreamedBlocksSum != 0) {
+        nStreamedBlocksSum = 0;
+        for (unsigned int i = 0; i < m_streamOutParts; i++) {
+            unsigned int nStreamedBlocks = 0;
+            // radius 0: every block is "outside"
+            const vh::vec3i far = worldToChunks({ (float)(m_minGridPos.x - 1), (float)(m_minGridPos.y - 1), (float)(m_minGridPos.z - 1) });
+            streamOutToCPU({ (float)far.x, (float)far.y, (float)far.z }, 0.0f, s_useParts, nStreamedBlocks);
+            nStreamedBlocksSum += nStreamedBlocks;
+        }
+    }
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:44-53
+void CUDASceneRepChunkGrid::streamOutToCPU(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks)
+{
+    s_posCamera = posCamera;
+    s_radius = radius;
+    streamOutToCPUPass0GPU(posCamera, radius, useParts, false);
+    streamOutToCPUPass1CPU(false);
+    nStreamedBlocks = s_nStreamdOutBlocks;
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:55-105
+void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded)
+{
+    std::unique_lock<std::mutex> lock(hMutexOut, std::defer_lock);
+    if (multiThreaded) {
+        hEventOutProduce.wait();
+        lock.lock();
+    }
+    s_posCamera = posCamera;
+    s_radius = radius;
+
+    const HashParams& hp = m_sceneRepHashSDF->getHashParams();
+    HashData& hd = m_sceneRepHashSDF->getHashData();
+    vhStream_t stream = m_sceneRepHashSDF->getStream();
+    const int32_t token = m_sceneRepHashSDF->nextLockToken(); // = resetHashBucketMutexCUDA
+    check(vh_memset(d_SDFBlockCounter, 0, sizeof(unsigned int), stream), "clearSDFBlockCounter");
+
+    const unsigned int numEntries = hp.m_hashNumBuckets * hp.m_hashBucketSize;
+    unsigned int threadsPerPart = (numEntries + m_streamOutParts - 1) / m_streamOutParts;
+    if (!useParts) threadsPerPart = numEntries;
+    const unsigned int start = useParts ? m_currentPart * threadsPerPart : 0;
+
+    const float cam[3] = { posCamera.x, posCamera.y, posCamera.z };
+    check(vh_stream_out_pass1(&hd, &hp, threadsPerPart, start, radius, cam, d_SDFBlockCounter, d_SDFBlockDescOutput,
+                              m_maxNumberOfSDFBlocksIntegrateFromGlobalHash, token, stream), "integrateFromGlobalHashPass1CUDA");
+    unsigned int nSDFBlockDescs = 0;
+    check(vh_memcpy_d2h(&nSDFBlockDescs, d_SDFBlockCounter, sizeof(unsigned int), stream), "getSDFBlockCounter");
+    if (nSDFBlockDescs >= m_maxNumberOfSDFBlocksIntegrateFromGlobalHash) {
+        if (multiThreaded) hEventOutProduce.set();
+        throw vh::Error(VH_ERR_STAGING_OVERFLOW,
+                        "not enough memory allocated for intermediate GPU buffer (wants to stream out more blocks than m_maxNumberOfSDFBlocksIntegrateFromGlobalHash)");
+    }
+    if (useParts) m_currentPart = (m_currentPart + 1) % m_streamOutParts;
+
+    if (nSDFBlockDescs != 0) {
+        check(vh_stream_out_pass2(&hd, &hp, d_SDFBlockDescOutput, (VhVoxel*)d_SDFBlockOutput, nSDFBlockDescs, stream), "integrateFromGlobalHashPass2CUDA");
+        hipStream_t s = (hipStream_t)stream;
+        checkHip(hipMemcpyAsync(h_SDFBlockDescOutput, d_SDFBlockDescOutput, sizeof(SDFBlockDesc) * nSDFBlockDescs, hipMemcpyDeviceToHost, s), "D2H descs");
+        checkHip(hipMemcpyAsync(h_SDFBlockOutput, d_SDFBlockOutput, sizeof(vh::SDFBlock) * nSDFBlockDescs, hipMemcpyDeviceToHost, s), "D2H blocks");
+        checkHip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    }
+    s_nStreamdOutBlocks = nSDFBlockDescs;
+
+    if (multiThreaded) hEventOutConsume.set();
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:107-124
+void CUDASceneRepChunkGrid::streamOutToCPUPass1CPU(bool multiThreaded)
+{
+    std::unique_lock<std::mutex> lock(hMutexOut, std::defer_lock);
+    if (multiThreaded) {
+        hEventOutConsume.wait();
+        lock.lock();
+        if (s_terminateThread) return; // avoid duplicate insertions when stop multi-threading is called
+    }
+    if (s_nStreamdOutBlocks != 0) integrateInChunkGrid(h_SDFBlockDescOutput, h_SDFBlockOutput, s_nStreamdOutBlocks);
+    if (multiThreaded) hEventOutProduce.set();
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:126-153
+void CUDASceneRepChunkGrid::integrateInChunkGrid(const SDFBlockDesc* desc, const vh::SDFBlock* block, unsigned int nSDFBlocks)
+{
+    const float voxelSize = m_sceneRepHashSDF->getHashParams().m_virtualVoxelSize;
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    for (unsigned int i = 0; i < nSDFBlocks; i++) {
+        const vh::vec3f posWorld = { (float)(desc[i].pos[0] * VH_SDF_BLOCK_SIZE) * voxelSize, (float)(desc[i].pos[1] * VH_SDF_BLOCK_SIZE) * voxelSize,
+                                     (float)(desc[i].pos[2] * VH_SDF_BLOCK_SIZE) * voxelSize };
+        const vh::vec3i chunk = worldToChunks(posWorld);
+        if (!isValidChunk(chunk)) {
+            std::fprintf(stderr, "Chunk out of bounds\n");
+            continue;
+        }
+        const unsigned int index = linearizeChunkPos(chunk);
+        auto it = m_grid.find(index);
+        if (it == m_grid.end()) it = m_grid.emplace(index, std::unique_ptr<ChunkDesc>(new ChunkDesc(m_initialChunkDescListSize))).first;
+        it->second->addSDFBlock(desc[i], block[i]);
+        setBit(index);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stream in: host -> GPU
+// ---------------------------------------------------------------------------
+
+// DSC/CUDASceneRepChunkGrid.cpp:155-161
+void CUDASceneRepChunkGrid::streamInToGPUAll()
+{
+    unsigned int nStreamedBlocks = 1;
+    while (nStreamedBlocks != 0) {
+        streamInToGPU(chunkToWorld({ 0, 0, 0 }), 1.1f * getGridRadiusInMeter(), s_useParts, nStreamedBlocks);
+    }
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:163-172
+void CUDASceneRepChunkGrid::streamInToGPUAll(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks)
+{
+    unsigned int nStreamedBlocksSum = 0;
+    unsigned int nBlock = 1;
+    while (nBlock != 0) {
+        streamInToGPU(posCamera, radius, useParts, nBlock);
+        nStreamedBlocksSum += nBlock;
+    }
+    nStreamedBlocks = nStreamedBlocksSum;
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:174-181
+void CUDASceneRepChunkGrid::streamInToGPUChunk(const vh::vec3i& chunkPos)
+{
+    unsigned int nStreamedBlocks = 1;
+    while (nStreamedBlocks != 0) streamInToGPU(chunkToWorld(chunkPos), 1.1f * getChunkRadiusInMeter(), true, nStreamedBlocks);
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:183-195
+void CUDASceneRepChunkGrid::streamInToGPUChunkNeighborhood(const vh::vec3i& c, int r)
+{
+    const vh::vec3i s = { std::max(c.x - r, m_minGridPos.x), std::max(c.y - r, m_minGridPos.y), std::max(c.z - r, m_minGridPos.z) };
+    const vh::vec3i e = { std::min(c.x + r, m_maxGridPos.x), std::min(c.y + r, m_maxGridPos.y), std::min(c.z + r, m_maxGridPos.z) };
+    for (int x = s.x; x < e.x; x++)
+        for (int y = s.y; y < e.y; y++)
+            for (int z = s.z; z < e.z; z++) streamInToGPUChunk({ x, y, z });
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:197-206
+void CUDASceneRepChunkGrid::streamInToGPU(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks)
+{
+    s_posCamera = posCamera;
+    s_radius = radius;
+    streamInToGPUPass0CPU(posCamera, radius, useParts, false);
+    streamInToGPUPass1GPU(false);
+    nStreamedBlocks = s_nStreamdInBlocks;
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:208-225
+void CUDASceneRepChunkGrid::streamInToGPUPass0CPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded)
+{
+    std::unique_lock<std::mutex> lock(hMutexIn, std::defer_lock);
+    if (multiThreaded) {
+        hEventInProduce.wait();
+        lock.lock();
+        if (s_terminateThread) return; // avoid duplicate insertions when stop multi-threading is called
+    }
+    s_nStreamdInBlocks = integrateInHash(posCamera, radius, useParts);
+    if (multiThreaded) hEventInConsume.set();
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:227-266
+void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
+{
+    std::unique_lock<std::mutex> lock(hMutexIn, std::defer_lock);
+    if (multiThreaded) {
+        hEventInConsume.wait();
+        lock.lock();
+    }
+    if (s_nStreamdInBlocks != 0) {
+        const HashParams& hp = m_sceneRepHashSDF->getHashParams();
+        HashData& hd = m_sceneRepHashSDF->getHashData();
+        vhStream_t stream = m_sceneRepHashSDF->getStream();
+        unsigned int heapCountPrev = 0; // index of the top free block
+        check(vh_memcpy_d2h(&heapCountPrev, hd.d_heapCounter, sizeof(unsigned int), stream), "heapCounter");
+        if (s_nStreamdInBlocks > heapCountPrev + 1u) {
+            if (multiThreaded) hEventInProduce.set();
+            throw vh::Error(VH_ERR_HEAP_EXHAUSTED, "stream-in: not enough free SDF blocks");
+        }
+        const int32_t token = m_sceneRepHashSDF->nextLockToken();
+        check(vh_stream_in_pass1(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, token, stream), "chunkToGlobalHashPass1CUDA");
+        check(vh_stream_in_pass2(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, (const VhVoxel*)d_SDFBlockInput, stream), "chunkToGlobalHashPass2CUDA");
+        // update heap counter (pinned source: stays valid until the copy ran)
+        h_counter[0] = heapCountPrev - s_nStreamdInBlocks;
+        checkHip(hipMemcpyAsync(hd.d_heapCounter, &h_counter[0], sizeof(unsigned int), hipMemcpyHostToDevice, (hipStream_t)stream), "heapCounter");
+        checkHip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+    }
+    if (multiThreaded) hEventInProduce.set();
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:268-311
+unsigned int CUDASceneRepChunkGrid::integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts)
+{
+    const vh::vec3i camChunk = worldToChunks(posCamera);
+    const vh::vec3i chunkRadius = meterToNumberOfChunksCeil(radius);
+    const vh::vec3i startChunk = { std::max(camChunk.x - chunkRadius.x, m_minGridPos.x), std::max(camChunk.y - chunkRadius.y, m_minGridPos.y),
+                                   std::max(camChunk.z - chunkRadius.z, m_minGridPos.z) };
+    const vh::vec3i endChunk = { std::min(camChunk.x + chunkRadius.x, m_maxGridPos.x - 1), std::min(camChunk.y + chunkRadius.y, m_maxGridPos.y - 1),
+                                 std::min(camChunk.z + chunkRadius.z, m_maxGridPos.z - 1) };
+    hipStream_t cs = (hipStream_t)m_copyStream;
+
+    unsigned int nSDFBlocks = 0;
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    for (int x = startChunk.x; x <= endChunk.x; x++) {
+        for (int y = startChunk.y; y <= endChunk.y; y++) {
+            for (int z = startChunk.z; z <= endChunk.z; z++) {
+                const unsigned int index = linearizeChunkPos({ x, y, z });
+                auto it = m_grid.find(index);
+                if (it == m_grid.end() || !it->second->isStreamedOut()) continue; // has been allocated and has streamed out blocks
+                if (!isChunkInSphere(delinearizeChunkIndex(index), posCamera, radius)) continue; // is in camera range
+                ChunkDesc& c = *it->second;
+                const unsigned int nBlock = c.getNElements();
+                if (nBlock + nSDFBlocks > m_maxNumberOfSDFBlocksIntegrateFromGlobalHash) {
+                    throw vh::Error(VH_ERR_STAGING_OVERFLOW,
+                                    "not enough memory allocated for intermediate GPU buffer (wants to stream in more blocks than m_maxNumberOfSDFBlocksIntegrateFromGlobalHash)");
+                }
+                // copy data to GPU through pinned staging, on the worker's own stream
+                std::memcpy(h_SDFBlockDescInput + nSDFBlocks, c.getSDFBlockDescs().data(), sizeof(SDFBlockDesc) * nBlock);
+                std::memcpy(h_SDFBlockInput + nSDFBlocks, c.getSDFBlocks().data(), sizeof(vh::SDFBlock) * nBlock);
+                checkHip(hipMemcpyAsync(d_SDFBlockDescInput + nSDFBlocks, h_SDFBlockDescInput + nSDFBlocks, sizeof(SDFBlockDesc) * nBlock, hipMemcpyHostToDevice, cs), "H2D descs");
+                checkHip(hipMemcpyAsync(d_SDFBlockInput + nSDFBlocks, h_SDFBlockInput + nSDFBlocks, sizeof(vh::SDFBlock) * nBlock, hipMemcpyHostToDevice, cs), "H2D blocks");
+                // remove data from CPU
+                c.clear();
+                resetBit(index);
+                nSDFBlocks += nBlock;
+                if (useParts) {
+                    checkHip(hipStreamSynchronize(cs), "hipStreamSynchronize");
+                    return nSDFBlocks; // only one chunk per frame
+                }
+            }
+        }
+    }
+    checkHip(hipStreamSynchronize(cs), "hipStreamSynchronize");
+    return nSDFBlocks;
+}
+
+// DSC/CUDASceneRepChunkGrid.cpp:313-341
+void CUDASceneRepChunkGrid::debugCheckForDuplicates() const
+{
+    struct PosHash {
+        size_t operator()(const std::array<int, 3>& v) const
+        {
+            return ((size_t)v[0] * 73856093u) ^ ((size_t)v[1] * 19349669u) ^ ((size_t)v[2] * 83492791u);
+        }
+    };
+    std::unordered_set<std::array<int, 3>, PosHash> seen;
+    const HashParams& hp = m_sceneRepHashSDF->getHashParams();
+    const size_t ne = (size_t)hp.m_hashBucketSize * hp.m_hashNumBuckets;
+    std::vector<HashEntry> hashCPU(ne);
+    check(vh_memcpy_d2h(hashCPU.data(), m_sceneRepHashSDF->getHashData().d_hash, sizeof(HashEntry) * ne, m_sceneRepHashSDF->getStream()), "debugCheckForDuplicates");
+    for (size_t i = 0; i < ne; i++) {
+        if (hashCPU[i].ptr != VH_FREE_ENTRY) {
+            if (!seen.insert({ hashCPU[i].pos[0], hashCPU[i].pos[1], hashCPU[i].pos[2] }).second)
+                throw vh::Error(VH_ERR_BAD_ARGUMENT, "Duplicate found in streaming hash data (in hash)");
+        }
+    }
+    std::lock_guard<std::mutex> l(m_gridMutex);
+    for (auto& kv : m_grid) {
+        for (const SDFBlockDesc& d : kv.second->getSDFBlockDescs()) {
+            if (!seen.insert({ d.pos[0], d.pos[1], d.pos[2] }).second)
+                throw vh::Error(VH_ERR_BAD_ARGUMENT, "Duplicate found in streaming hash data (in grid)");
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// .hashgrid (DSC/CUDASceneRepChunkGrid.h:456-548; mLib BinaryDataStreamFile:
+// raw little-endian PODs, std::vector<T> = UINT64 count + raw elements,
+// binaryDataStream.h:156-163,273-281; vec3 = 3 raw scalars)
+// ---------------------------------------------------------------------------
+
+namespace {
+const unsigned int kHashGridVersion = 1;
+template <class T> bool wr(FILE* f, const T& v) { return std::fwrite(&v, sizeof(T), 1, f) == 1; }
+template <class T> bool rd(FILE* f, T& v) { return std::fread(&v, sizeof(T), 1, f) == 1; }
+} // namespace
+
+void CUDASceneRepChunkGrid::saveToFile(const std::string& filename, const vh::vec3f& camPos, float radius)
+{
+    const bool wasRunning = !s_terminateThread;
+    stopMultiThreading();
+    streamOutToCPUAll();
+
+    FILE* f = std::fopen(filename.c_str(), "wb");
+    if (!f) throw vh::Error(VH_ERR_IO, "cannot open " + filename);
+    bool ok = true;
+    {
+        std::lock_guard<std::mutex> l(m_gridMutex);
+        const float voxelSize = m_sceneRepHashSDF->getHashParams().m_virtualVoxelSize;
+        ok = ok && wr(f, kHashGridVersion) && wr(f, voxelSize) && wr(f, m_voxelExtents) && wr(f, m_gridDimensions) && wr(f, m_minGridPos) &&
+             wr(f, m_maxGridPos) && wr(f, m_initialChunkDescListSize);
+        std::vector<unsigned int> keys;
+        for (auto& kv : m_grid) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end());
+        const unsigned int numOccupiedChunks = (unsigned int)keys.size();
+        ok = ok && wr(f, numOccupiedChunks);
+        for (unsigned int k : keys) {
+            const ChunkDesc& c = *m_grid.at(k);
+            const uint64_t nb = c.getSDFBlocks().size(), nd = c.getSDFBlockDescs().size();
+            ok = ok && wr(f, k) && wr(f, nb);
+            if (nb) ok = ok && std::fwrite(c.getSDFBlocks().data(), sizeof(vh::SDFBlock), nb, f) == nb;
+            ok = ok && wr(f, nd);
+            if (nd) ok = ok && std::fwrite(c.getSDFBlockDescs().data(), sizeof(SDFBlockDesc), nd, f) == nd;
+        }
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) throw vh::Error(VH_ERR_IO, "write error on " + filename);
+
+    unsigned int nStreamedBlocks;
+    streamInToGPUAll(camPos, radius, true, nStreamedBlocks);
+    if (wasRunning) startMultiThreading();
+}
+
+void CUDASceneRepChunkGrid::loadFromFile(const std::string& filename, const vh::vec3f& camPos, float radius)
+{
+    (void)camPos; (void)radius;
+    const bool wasRunning = !s_terminateThread;
+    stopMultiThreading();
+    streamOutToCPUAll();
+    clearGrid();
+    {
+        std::lock_guard<std::mutex> l(m_gridMutex);
+        std::fill(m_bitMask.begin(), m_bitMask.end(), 0u);
+        m_bitMaskDirty = true;
+    }
+
+    FILE* f = std::fopen(filename.c_str(), "rb");
+    if (!f) throw vh::Error(VH_ERR_IO, "cannot open " + filename);
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{ f };
+
+    unsigned int version = 0, listSize = 0, numOccupiedChunks = 0;
+    float voxelSize = 0.0f;
+    vh::vec3f ext = { 0, 0, 0 };
+    vh::vec3i dims = { 0, 0, 0 }, minPos = { 0, 0, 0 }, maxPos = { 0, 0, 0 };
+    if (!(rd(f, version) && rd(f, voxelSize) && rd(f, ext) && rd(f, dims) && rd(f, minPos) && rd(f, maxPos) && rd(f, listSize)))
+        throw vh::Error(VH_ERR_IO, "invalid read; probably wrong file name (" + filename + ")?");
+    if (version != kHashGridVersion)
+        throw vh::Error(VH_ERR_VERSION_MISMATCH, "hashgrid versions don't match - found " + std::to_string(version) + " should be " + std::to_string(kHashGridVersion));
+    if (!rd(f, numOccupiedChunks)) throw vh::Error(VH_ERR_IO, "invalid read");
+    if (ext.x != m_voxelExtents.x || ext.y != m_voxelExtents.y || ext.z != m_voxelExtents.z) throw vh::Error(VH_ERR_BAD_ARGUMENT, "voxel extends don't match");
+    if (dims.x != m_gridDimensions.x || dims.y != m_gridDimensions.y || dims.z != m_gridDimensions.z) throw vh::Error(VH_ERR_BAD_ARGUMENT, "grid dimensions don't match");
+    if (minPos.x != m_minGridPos.x || minPos.y != m_minGridPos.y || minPos.z != m_minGridPos.z) throw vh::Error(VH_ERR_BAD_ARGUMENT, "minGridPos doesn't match");
+    if (maxPos.x != m_maxGridPos.x || maxPos.y != m_maxGridPos.y || maxPos.z != m_maxGridPos.z) throw vh::Error(VH_ERR_BAD_ARGUMENT, "maxGridPos doesn't match");
+    if (listSize != m_initialChunkDescListSize) throw vh::Error(VH_ERR_BAD_ARGUMENT, "initial chunkListSize doesn't match");
+
+    {
+        std::lock_guard<std::mutex> l(m_gridMutex);
+        const size_t nChunks = (size_t)m_gridDimensions.x * m_gridDimensions.y * m_gridDimensions.z;
+        for (unsigned int i = 0; i < numOccupiedChunks; i++) {
+            unsigned int index = 0;
+            uint64_t nb = 0, nd = 0;
+            if (!rd(f, index) || index >= nChunks) throw vh::Error(VH_ERR_IO, "invalid chunk index");
+            std::unique_ptr<ChunkDesc> c(new ChunkDesc(m_initialChunkDescListSize));
+            if (!rd(f, nb)) throw vh::Error(VH_ERR_IO, "invalid read");
+            c->getSDFBlocks().resize(nb);
+            if (nb && std::fread(c->getSDFBlocks().data(), sizeof(vh::SDFBlock), nb, f) != nb) throw vh::Error(VH_ERR_IO, "invalid read");
+            if (!rd(f, nd)) throw vh::Error(VH_ERR_IO, "invalid read");
+            c->getSDFBlockDescs().resize(nd);
+            if (nd && std::fread(c->getSDFBlockDescs().data(), sizeof(SDFBlockDesc), nd, f) != nd) throw vh::Error(VH_ERR_IO, "invalid read");
+            // the reference leaves the bit mask cleared after a load (alloc may then re-create blocks
+            // of streamed-out chunks); here the mask follows the grid content
+            if (c->isStreamedOut()) setBit(index);
+            m_grid[index] = std::move(c);
+        }
+    }
+    if (wasRunning) startMultiThreading();
+}

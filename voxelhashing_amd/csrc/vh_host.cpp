@@ -1,0 +1,595 @@
+// vh_host.cpp -- host side of the engine: memory ownership, the
+// CUDASceneRepHashSDF and CUDARayCastSDF classes (include/vh.hpp) and the
+// small utility entry points of the C ABI.
+//
+// Behavioural contract: DSC/CUDASceneRepHashSDF.h, DSC/CUDARayCastSDF.{h,cpp},
+// DSC/VoxelUtilHashSDF.h:113-181 (DSC/ = /root/reference/DepthSensingCUDA/Source/).
+// Unlike the reference frame loop there is no blocking host<->device round
+// trip per frame in online mode: block counts stay on the device (persistent
+// grid in the fused integrate kernel), bucket locks use a running epoch instead
+// of a per-pass mutex reset, parameters are kernel arguments.
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <climits>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/vh.hpp"
+#include "vh_host_util.hpp"
+#include "vh_stage_timer.hpp"
+
+namespace {
+
+inline void check(int code, const char* what)
+{
+    if (code != 0) throw vh::Error(code, std::string(what) + ": " + vh_error_string(code));
+}
+inline void checkHip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw vh::Error(-(int)e, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// utility C ABI
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+const char* vh_version(void) { return "voxelhashing_amd 0.1.0 (gfx950)"; }
+
+const char* vh_error_string(int code)
+{
+    if (code < 0) return hipGetErrorString((hipError_t)(-code));
+    switch (code) {
+    case VH_OK: return "ok";
+    case VH_ERR_HEAP_EXHAUSTED: return "SDF block heap exhausted";
+    case VH_ERR_STAGING_OVERFLOW: return "streaming staging buffer overflow";
+    case VH_ERR_INSERT_FAILED: return "hash insert failed";
+    case VH_ERR_BAD_ARGUMENT: return "bad argument";
+    case VH_ERR_VERSION_MISMATCH: return "hashgrid version mismatch";
+    case VH_ERR_IO: return "file i/o error";
+    default: return "unknown error";
+    }
+}
+
+int vh_malloc(void** devPtr, size_t bytes)
+{
+    if (!devPtr) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipMalloc(devPtr, bytes));
+    return VH_OK;
+}
+int vh_free(void* devPtr)
+{
+    VH_HIP(hipFree(devPtr));
+    return VH_OK;
+}
+int vh_memcpy_h2d(void* dst, const void* src, size_t bytes, vhStream_t stream)
+{
+    VH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    VH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_memcpy_d2h(void* dst, const void* src, size_t bytes, vhStream_t stream)
+{
+    VH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    VH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream)
+{
+    VH_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return VH_OK;
+}
+int vh_stream_synchronize(vhStream_t stream)
+{
+    VH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_device_synchronize(void)
+{
+    VH_HIP(hipDeviceSynchronize());
+    return VH_OK;
+}
+
+// HashData::allocate, DSC/VoxelUtilHashSDF.h:113-139
+int vh_hash_data_alloc(VhHashData* hd, const VhHashParams* hp)
+{
+    if (!hd || !hp || hp->m_hashNumBuckets == 0 || hp->m_numSDFBlocks == 0) return VH_ERR_BAD_ARGUMENT;
+    if (hp->m_hashBucketSize != VH_HASH_BUCKET_SIZE || hp->m_SDFBlockSize != VH_SDF_BLOCK_SIZE) return VH_ERR_BAD_ARGUMENT;
+    // ptr = blockId*512 must fit an int; entry indices must fit 32 bits
+    if ((uint64_t)hp->m_numSDFBlocks * VH_SDF_BLOCK_VOXELS > (uint64_t)INT_MAX) return VH_ERR_BAD_ARGUMENT;
+    if ((uint64_t)hp->m_hashNumBuckets * VH_HASH_BUCKET_SIZE > (uint64_t)UINT_MAX / 2) return VH_ERR_BAD_ARGUMENT;
+    std::memset(hd, 0, sizeof(*hd));
+    const size_t nb = hp->m_hashNumBuckets, ne = nb * VH_HASH_BUCKET_SIZE, nblk = hp->m_numSDFBlocks;
+    int err = 0;
+#define VH_ALLOC(field, bytes)                                              \
+    if (!err) {                                                             \
+        hipError_t e_ = hipMalloc((void**)&hd->field, (bytes));             \
+        if (e_ != hipSuccess) { hd->field = nullptr; err = -(int)e_; }      \
+    }
+    VH_ALLOC(d_heap, sizeof(uint32_t) * nblk)
+    VH_ALLOC(d_heapCounter, sizeof(uint32_t))
+    VH_ALLOC(d_hash, sizeof(VhHashEntry) * ne)
+    VH_ALLOC(d_hashDecision, sizeof(int32_t) * ne)
+    VH_ALLOC(d_hashDecisionPrefix, sizeof(int32_t) * ne)
+    VH_ALLOC(d_hashCompactified, sizeof(VhHashEntry) * ne)
+    VH_ALLOC(d_hashCompactifiedCounter, sizeof(int32_t))
+    VH_ALLOC(d_SDFBlocks, sizeof(VhVoxel) * nblk * VH_SDF_BLOCK_VOXELS)
+    VH_ALLOC(d_hashBucketMutex, sizeof(int32_t) * nb)
+    VH_ALLOC(d_bucketCount, sizeof(uint32_t) * nb)
+    VH_ALLOC(d_bucketBits, sizeof(uint32_t) * ((nb + 31) / 32))
+    VH_ALLOC(d_state, sizeof(uint32_t) * VH_STATE_WORDS)
+#undef VH_ALLOC
+    if (err) {
+        vh_hash_data_free(hd);
+        return err;
+    }
+    hd->m_bIsOnGPU = 1;
+    return VH_OK;
+}
+
+// HashData::free, DSC/VoxelUtilHashSDF.h:148-181
+int vh_hash_data_free(VhHashData* hd)
+{
+    if (!hd) return VH_ERR_BAD_ARGUMENT;
+    void* ptrs[] = { hd->d_heap, hd->d_heapCounter, hd->d_hash, hd->d_hashDecision, hd->d_hashDecisionPrefix,
+                     hd->d_hashCompactified, hd->d_hashCompactifiedCounter, hd->d_SDFBlocks, hd->d_hashBucketMutex,
+                     hd->d_bucketCount, hd->d_bucketBits, hd->d_state };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    std::memset(hd, 0, sizeof(*hd));
+    return VH_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// mat4f
+// ---------------------------------------------------------------------------
+
+namespace vh {
+
+mat4f mat4f::identity()
+{
+    mat4f r;
+    for (int i = 0; i < 16; i++) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    return r;
+}
+
+// float4x4::getInverse (DSC/cuda_SimpleMatrixUtil.h:944-1069): cofactors as
+// six signed triple products summed in the reference's order, then scaled by
+// 1/det.  Host code is compiled with -ffp-contract=off like the kernels.
+mat4f mat4f::getInverse() const
+{
+    static const signed char T[16][6][4] = {
+        { {+1,5,10,15}, {-1,5,11,14}, {-1,9,6,15}, {+1,9,7,14}, {+1,13,6,11}, {-1,13,7,10} },
+        { {-1,1,10,15}, {+1,1,11,14}, {+1,9,2,15}, {-1,9,3,14}, {-1,13,2,11}, {+1,13,3,10} },
+        { {+1,1,6,15}, {-1,1,7,14}, {-1,5,2,15}, {+1,5,3,14}, {+1,13,2,7}, {-1,13,3,6} },
+        { {-1,1,6,11}, {+1,1,7,10}, {+1,5,2,11}, {-1,5,3,10}, {-1,9,2,7}, {+1,9,3,6} },
+        { {-1,4,10,15}, {+1,4,11,14}, {+1,8,6,15}, {-1,8,7,14}, {-1,12,6,11}, {+1,12,7,10} },
+        { {+1,0,10,15}, {-1,0,11,14}, {-1,8,2,15}, {+1,8,3,14}, {+1,12,2,11}, {-1,12,3,10} },
+        { {-1,0,6,15}, {+1,0,7,14}, {+1,4,2,15}, {-1,4,3,14}, {-1,12,2,7}, {+1,12,3,6} },
+        { {+1,0,6,11}, {-1,0,7,10}, {-1,4,2,11}, {+1,4,3,10}, {+1,8,2,7}, {-1,8,3,6} },
+        { {+1,4,9,15}, {-1,4,11,13}, {-1,8,5,15}, {+1,8,7,13}, {+1,12,5,11}, {-1,12,7,9} },
+        { {-1,0,9,15}, {+1,0,11,13}, {+1,8,1,15}, {-1,8,3,13}, {-1,12,1,11}, {+1,12,3,9} },
+        { {+1,0,5,15}, {-1,0,7,13}, {-1,4,1,15}, {+1,4,3,13}, {+1,12,1,7}, {-1,12,3,5} },
+        { {-1,0,5,11}, {+1,0,7,9}, {+1,4,1,11}, {-1,4,3,9}, {-1,8,1,7}, {+1,8,3,5} },
+        { {-1,4,9,14}, {+1,4,10,13}, {+1,8,5,14}, {-1,8,6,13}, {-1,12,5,10}, {+1,12,6,9} },
+        { {+1,0,9,14}, {-1,0,10,13}, {-1,8,1,14}, {+1,8,2,13}, {+1,12,1,10}, {-1,12,2,9} },
+        { {-1,0,5,14}, {+1,0,6,13}, {+1,4,1,14}, {-1,4,2,13}, {-1,12,1,6}, {+1,12,2,5} },
+        { {+1,0,5,10}, {-1,0,6,9}, {-1,4,1,10}, {+1,4,2,9}, {+1,8,1,6}, {-1,8,2,5} },
+    };
+    float inv[16];
+    for (int n = 0; n < 16; n++) {
+        float acc = 0.0f;
+        for (int t = 0; t < 6; t++) {
+            const float p = m[T[n][t][1]] * m[T[n][t][2]] * m[T[n][t][3]];
+            if (t == 0) acc = (T[n][t][0] > 0) ? p : -p;
+            else acc = (T[n][t][0] > 0) ? acc + p : acc - p;
+        }
+        inv[n] = acc;
+    }
+    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    const float detr = 1.0f / det;
+    mat4f r;
+    for (int n = 0; n < 16; n++) r.m[n] = inv[n] * detr;
+    return r;
+}
+
+// float4x4::operator*, DSC/cuda_SimpleMatrixUtil.h:861-885
+mat4f mat4f::operator*(const mat4f& o) const
+{
+    mat4f r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.m[4 * i + j] = m[4 * i + 0] * o.m[j] + m[4 * i + 1] * o.m[4 + j] + m[4 * i + 2] * o.m[8 + j] + m[4 * i + 3] * o.m[12 + j];
+    return r;
+}
+
+vec3f mat4f::transformPoint(const vec3f& v) const
+{
+    vec3f r;
+    r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * 1.0f;
+    r.y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * 1.0f;
+    r.z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * 1.0f;
+    return r;
+}
+
+} // namespace vh
+
+// ---------------------------------------------------------------------------
+// CUDASceneRepHashSDF
+// ---------------------------------------------------------------------------
+
+enum { ST_ALLOC = 0, ST_COMPACTIFY = 1, ST_INTEGRATE = 2, ST_RAYCAST = 0, ST_NORMALS = 1 };
+
+VhSceneOptions CUDASceneRepHashSDF::defaultOptions()
+{
+    // DSC reference defaults (zParametersDefault.txt:64-67) except GC, which the
+    // measurement contract enables
+    VhSceneOptions o;
+    std::memset(&o, 0, sizeof(o));
+    o.s_offlineProcessing = 0;
+    o.s_garbageCollectionEnabled = 1;
+    o.s_timingsDetailledEnabled = 0;
+    o.s_useReferenceLaunchSequence = 0;
+    o.s_garbageCollectionStarve = 15;
+    o.s_streamingOutParts = 80;
+    return o;
+}
+
+CUDASceneRepHashSDF::CUDASceneRepHashSDF(const HashParams& params)
+    : m_options(defaultOptions()), m_stream(nullptr)
+{
+    create(params);
+}
+
+CUDASceneRepHashSDF::CUDASceneRepHashSDF(const HashParams& params, const VhSceneOptions& options, vhStream_t stream)
+    : m_options(options), m_stream(stream)
+{
+    create(params);
+}
+
+CUDASceneRepHashSDF::~CUDASceneRepHashSDF() { destroy(); }
+
+void CUDASceneRepHashSDF::create(const HashParams& params)
+{
+    m_hashParams = params;
+    m_numIntegratedFrames = 0;
+    m_lockEpoch = 0;
+    h_occupied = nullptr;
+    m_occupiedEvent = nullptr;
+    m_occupiedPending = false;
+    m_timer = new VhStageTimer(3);
+    std::memset(&m_hashData, 0, sizeof(m_hashData));
+    check(vh_hash_data_alloc(&m_hashData, &m_hashParams), "HashData::allocate");
+    checkHip(hipHostMalloc((void**)&h_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+    *h_occupied = 0;
+    hipEvent_t ev;
+    checkHip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    m_occupiedEvent = ev;
+    reset();
+}
+
+void CUDASceneRepHashSDF::destroy()
+{
+    (void)hipStreamSynchronize((hipStream_t)m_stream);
+    delete m_timer;
+    m_timer = nullptr;
+    if (m_occupiedEvent) (void)hipEventDestroy((hipEvent_t)m_occupiedEvent);
+    if (h_occupied) (void)hipHostFree(h_occupied);
+    vh_hash_data_free(&m_hashData);
+}
+
+// DSC/CUDASceneRepHashSDF.h:101-109
+void CUDASceneRepHashSDF::reset()
+{
+    m_numIntegratedFrames = 0;
+    const vh::mat4f id = vh::mat4f::identity();
+    std::memcpy(m_hashParams.m_rigidTransform, id.m, sizeof(id.m));
+    std::memcpy(m_hashParams.m_rigidTransformInverse, id.m, sizeof(id.m));
+    m_hashParams.m_numOccupiedBlocks = 0;
+    pollOccupiedCount(true);
+    *h_occupied = 0;
+    m_lockEpoch = 0;
+    check(vh_reset(&m_hashData, &m_hashParams, m_stream), "resetCUDA");
+}
+
+int32_t CUDASceneRepHashSDF::nextLockToken()
+{
+    // tokens are positive, so they never equal FREE_ENTRY(-2) / LOCK_ENTRY(-1)
+    if (m_lockEpoch == INT32_MAX - 1) {
+        check(vh_reset_bucket_mutex(&m_hashData, &m_hashParams, m_stream), "resetHashBucketMutexCUDA");
+        m_lockEpoch = 0;
+    }
+    return ++m_lockEpoch;
+}
+
+// DSC/CUDASceneRepHashSDF.h:85-88
+void CUDASceneRepHashSDF::setLastRigidTransform(const vh::mat4f& t)
+{
+    std::memcpy(m_hashParams.m_rigidTransform, t.m, sizeof(t.m));
+    const vh::mat4f inv = t.getInverse();
+    std::memcpy(m_hashParams.m_rigidTransformInverse, inv.m, sizeof(inv.m));
+}
+
+// DSC/CUDASceneRepHashSDF.h:90-93
+void CUDASceneRepHashSDF::setLastRigidTransformAndCompactify(const vh::mat4f& t, const DepthCameraParams& cp)
+{
+    setLastRigidTransform(t);
+    compactifyHashEntries(cp);
+}
+
+const vh::mat4f CUDASceneRepHashSDF::getLastRigidTransform() const
+{
+    vh::mat4f r;
+    std::memcpy(r.m, m_hashParams.m_rigidTransform, sizeof(r.m));
+    return r;
+}
+
+void CUDASceneRepHashSDF::pollOccupiedCount(bool block)
+{
+    if (!m_occupiedPending) return;
+    hipEvent_t ev = (hipEvent_t)m_occupiedEvent;
+    if (block) {
+        checkHip(hipEventSynchronize(ev), "hipEventSynchronize");
+    } else if (hipEventQuery(ev) != hipSuccess) {
+        return;
+    }
+    m_hashParams.m_numOccupiedBlocks = *h_occupied;
+    m_occupiedPending = false;
+}
+
+const HashParams& CUDASceneRepHashSDF::getHashParams()
+{
+    pollOccupiedCount(false);
+    return m_hashParams;
+}
+
+unsigned int CUDASceneRepHashSDF::getNumOccupiedBlocks()
+{
+    pollOccupiedCount(true);
+    return m_hashParams.m_numOccupiedBlocks;
+}
+
+// DSC/CUDASceneRepHashSDF.h:122-126
+unsigned int CUDASceneRepHashSDF::getHeapFreeCount()
+{
+    unsigned int count = 0;
+    check(vh_memcpy_d2h(&count, m_hashData.d_heapCounter, sizeof(count), m_stream), "getHeapFreeCount");
+    return count + 1;
+}
+
+// DSC/CUDASceneRepHashSDF.h:64-83
+void CUDASceneRepHashSDF::integrate(const vh::mat4f& lastRigidTransform, const DepthCameraData& cam,
+                                    const DepthCameraParams& cp, const unsigned int* d_bitMask)
+{
+    setLastRigidTransform(lastRigidTransform);
+    alloc(cam, cp, d_bitMask);
+    compactifyHashEntries(cp);
+    if (m_options.s_useReferenceLaunchSequence) {
+        integrateDepthMap(cam, cp);
+        garbageCollect(cp);
+    } else {
+        // integrate -> [starve] -> identify -> free in one pass over the voxels
+        uint32_t flags = 0;
+        if (m_options.s_garbageCollectionEnabled) {
+            flags |= VH_FUSED_GC;
+            if (m_numIntegratedFrames > 0 && m_options.s_garbageCollectionStarve != 0 &&
+                m_numIntegratedFrames % m_options.s_garbageCollectionStarve == 0)
+                flags |= VH_FUSED_STARVE;
+        }
+        const bool timed = m_options.s_timingsDetailledEnabled;
+        if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
+        check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), m_stream), "integrate (fused)");
+        if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
+    }
+    m_numIntegratedFrames++;
+}
+
+// DSC/CUDASceneRepHashSDF.h:247-279
+void CUDASceneRepHashSDF::alloc(const DepthCameraData& cam, const DepthCameraParams& cp, const unsigned int* d_bitMask)
+{
+    const bool timed = m_options.s_timingsDetailledEnabled;
+    if (timed) m_timer->start(ST_ALLOC, (hipStream_t)m_stream);
+    if (m_options.s_offlineProcessing) {
+        // allocate until all blocks are allocated (one blocking read-back per pass, as the reference)
+        unsigned int prevFree = getHeapFreeCount();
+        while (true) {
+            check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), m_stream), "allocCUDA");
+            unsigned int currFree = getHeapFreeCount();
+            if (prevFree != currFree) prevFree = currFree;
+            else break;
+        }
+    } else {
+        check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), m_stream), "allocCUDA");
+    }
+    if (timed) m_timer->stop(ST_ALLOC, (hipStream_t)m_stream);
+}
+
+// DSC/CUDASceneRepHashSDF.h:282-315
+void CUDASceneRepHashSDF::compactifyHashEntries(const DepthCameraParams& cp)
+{
+    const bool timed = m_options.s_timingsDetailledEnabled;
+    if (timed) m_timer->start(ST_COMPACTIFY, (hipStream_t)m_stream);
+    const bool needHostCount = m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence;
+    if (needHostCount) {
+        pollOccupiedCount(true);
+        uint32_t n = 0;
+        check(vh_compactify(&m_hashData, &m_hashParams, &cp, &n, m_stream), "compactifyHashAllInOneCUDA");
+        m_hashParams.m_numOccupiedBlocks = n;
+    } else {
+        check(vh_compactify(&m_hashData, &m_hashParams, &cp, nullptr, m_stream), "compactifyHashAllInOneCUDA");
+        // non-blocking read-back for getHashParams(); skipped while the previous one is in flight
+        pollOccupiedCount(false);
+        if (!m_occupiedPending) {
+            checkHip(hipMemcpyAsync(h_occupied, m_hashData.d_hashCompactifiedCounter, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                    (hipStream_t)m_stream), "hipMemcpyAsync");
+            checkHip(hipEventRecord((hipEvent_t)m_occupiedEvent, (hipStream_t)m_stream), "hipEventRecord");
+            m_occupiedPending = true;
+        }
+    }
+    if (timed) m_timer->stop(ST_COMPACTIFY, (hipStream_t)m_stream);
+}
+
+// DSC/CUDASceneRepHashSDF.h:317-325
+void CUDASceneRepHashSDF::integrateDepthMap(const DepthCameraData& cam, const DepthCameraParams& cp)
+{
+    const bool timed = m_options.s_timingsDetailledEnabled;
+    if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
+    check(vh_integrate(&m_hashData, &m_hashParams, &cam, &cp, m_stream), "integrateDepthMapCUDA");
+    if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
+}
+
+// DSC/CUDASceneRepHashSDF.h:327-339
+void CUDASceneRepHashSDF::garbageCollect(const DepthCameraParams& cp)
+{
+    if (!m_options.s_garbageCollectionEnabled) return;
+    if (m_numIntegratedFrames > 0 && m_options.s_garbageCollectionStarve != 0 &&
+        m_numIntegratedFrames % m_options.s_garbageCollectionStarve == 0) {
+        check(vh_starve(&m_hashData, &m_hashParams, m_stream), "starveVoxelsKernelCUDA");
+    }
+    check(vh_gc_identify(&m_hashData, &m_hashParams, &cp, m_stream), "garbageCollectIdentifyCUDA");
+    check(vh_reset_bucket_mutex(&m_hashData, &m_hashParams, m_stream), "resetHashBucketMutexCUDA");
+    m_lockEpoch = 0; // the array was reset: epochs may restart
+    check(vh_gc_free(&m_hashData, &m_hashParams, nextLockToken(), m_stream), "garbageCollectFreeCUDA");
+}
+
+void CUDASceneRepHashSDF::getState(uint32_t out[VH_STATE_WORDS])
+{
+    check(vh_memcpy_d2h(out, m_hashData.d_state, sizeof(uint32_t) * VH_STATE_WORDS, m_stream), "getState");
+}
+
+void CUDASceneRepHashSDF::getTimings(double out[4])
+{
+    m_timer->resolve((hipStream_t)m_stream);
+    out[0] = m_timer->totalMs[ST_ALLOC];
+    out[1] = m_timer->totalMs[ST_COMPACTIFY];
+    out[2] = m_timer->totalMs[ST_INTEGRATE];
+    out[3] = (double)m_timer->count[ST_INTEGRATE];
+}
+
+// DSC/CUDASceneRepHashSDF.h:129-233
+void CUDASceneRepHashSDF::debugHash(unsigned int report[4])
+{
+    const size_t ne = (size_t)m_hashParams.m_hashBucketSize * m_hashParams.m_hashNumBuckets;
+    const unsigned int nblk = m_hashParams.m_numSDFBlocks;
+    std::vector<HashEntry> hashCPU(ne);
+    std::vector<unsigned int> heapCPU(nblk);
+    unsigned int heapCounterCPU = 0;
+    check(vh_memcpy_d2h(&heapCounterCPU, m_hashData.d_heapCounter, sizeof(unsigned int), m_stream), "debugHash");
+    heapCounterCPU++; // points to the first free entry: number of blocks is one more
+    check(vh_memcpy_d2h(heapCPU.data(), m_hashData.d_heap, sizeof(unsigned int) * nblk, m_stream), "debugHash");
+    check(vh_memcpy_d2h(hashCPU.data(), m_hashData.d_hash, sizeof(HashEntry) * ne, m_stream), "debugHash");
+
+    if (heapCounterCPU > nblk) throw vh::Error(VH_ERR_HEAP_EXHAUSTED, "ERROR: heap counter out of range");
+    std::vector<int> pointersFreeVec(nblk, 0);
+    for (unsigned int i = 0; i < heapCounterCPU; i++) {
+        if (heapCPU[i] >= nblk) throw vh::Error(VH_ERR_BAD_ARGUMENT, "ERROR: heap holds an out-of-range block id");
+        if (pointersFreeVec[heapCPU[i]] == VH_FREE_ENTRY) throw vh::Error(VH_ERR_BAD_ARGUMENT, "ERROR: duplicate free pointers in heap array");
+        pointersFreeVec[heapCPU[i]] = VH_FREE_ENTRY;
+    }
+
+    struct PosHash {
+        size_t operator()(const std::array<int, 3>& v) const
+        {
+            return ((size_t)v[0] * 73856093u) ^ ((size_t)v[1] * 19349669u) ^ ((size_t)v[2] * 83492791u);
+        }
+    };
+    std::unordered_set<std::array<int, 3>, PosHash> seen;
+    unsigned int numOccupied = 0, numMinusOne = 0, duplicates = 0;
+    for (size_t i = 0; i < ne; i++) {
+        if (hashCPU[i].ptr == VH_LOCK_ENTRY) { numMinusOne++; continue; }
+        if (hashCPU[i].ptr != VH_FREE_ENTRY) {
+            numOccupied++;
+            if (!seen.insert({ hashCPU[i].pos[0], hashCPU[i].pos[1], hashCPU[i].pos[2] }).second) duplicates++;
+            const unsigned int blk = (unsigned int)hashCPU[i].ptr / VH_SDF_BLOCK_VOXELS;
+            if (blk >= nblk) throw vh::Error(VH_ERR_BAD_ARGUMENT, "ERROR: entry points outside the SDF block array");
+            if (pointersFreeVec[blk] == VH_FREE_ENTRY)
+                throw vh::Error(VH_ERR_BAD_ARGUMENT, "ERROR: ptr is on free heap, but also marked as an allocated entry");
+            if (pointersFreeVec[blk] == VH_LOCK_ENTRY)
+                throw vh::Error(VH_ERR_BAD_ARGUMENT, "ERROR: two entries share one SDF block");
+            pointersFreeVec[blk] = VH_LOCK_ENTRY;
+        }
+    }
+    unsigned int numHeapFree = 0, numHeapOccupied = 0;
+    for (unsigned int i = 0; i < nblk; i++) {
+        if (pointersFreeVec[i] == VH_FREE_ENTRY) numHeapFree++;
+        else if (pointersFreeVec[i] == VH_LOCK_ENTRY) numHeapOccupied++;
+        else throw vh::Error(VH_ERR_BAD_ARGUMENT, "memory leak detected: neither free nor allocated");
+    }
+    if (numHeapFree + numHeapOccupied != nblk) throw vh::Error(VH_ERR_BAD_ARGUMENT, "HEAP CORRUPTED");
+    if (report) {
+        report[0] = numOccupied;
+        report[1] = heapCounterCPU;
+        report[2] = duplicates;
+        report[3] = numMinusOne;
+    }
+    if (duplicates) throw vh::Error(VH_ERR_BAD_ARGUMENT, "ERROR: duplicate block positions in hash");
+}
+
+// ---------------------------------------------------------------------------
+// CUDARayCastSDF
+// ---------------------------------------------------------------------------
+
+CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
+    : m_params(params), m_stream(stream), m_timer(nullptr)
+{
+    std::memset(&m_data, 0, sizeof(m_data));
+    const size_t n = (size_t)params.m_width * params.m_height;
+    // RayCastData::allocate, DSC/RayCastSDFUtil.h:56-61
+    checkHip(hipMalloc((void**)&m_data.d_depth, sizeof(float) * n), "RayCastData::allocate");
+    checkHip(hipMalloc((void**)&m_data.d_depth4, sizeof(float) * 4 * n), "RayCastData::allocate");
+    checkHip(hipMalloc((void**)&m_data.d_normals, sizeof(float) * 4 * n), "RayCastData::allocate");
+    checkHip(hipMalloc((void**)&m_data.d_colors, sizeof(float) * 4 * n), "RayCastData::allocate");
+}
+
+CUDARayCastSDF::~CUDARayCastSDF()
+{
+    (void)hipStreamSynchronize((hipStream_t)m_stream);
+    delete m_timer;
+    if (m_data.d_depth) (void)hipFree(m_data.d_depth);
+    if (m_data.d_depth4) (void)hipFree(m_data.d_depth4);
+    if (m_data.d_normals) (void)hipFree(m_data.d_normals);
+    if (m_data.d_colors) (void)hipFree(m_data.d_colors);
+}
+
+void CUDARayCastSDF::setTiming(bool on)
+{
+    if (on && !m_timer) m_timer = new VhStageTimer(2);
+    if (!on && m_timer) { delete m_timer; m_timer = nullptr; }
+}
+
+void CUDARayCastSDF::getTimings(double out[3])
+{
+    out[0] = out[1] = out[2] = 0.0;
+    if (!m_timer) return;
+    m_timer->resolve((hipStream_t)m_stream);
+    out[0] = m_timer->totalMs[ST_RAYCAST];
+    out[1] = m_timer->totalMs[ST_NORMALS];
+    out[2] = (double)m_timer->count[ST_RAYCAST];
+}
+
+// DSC/CUDARayCastSDF.cpp:38-72 with rayIntervalSplatting :84-100 (view matrices only)
+void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashParams, const DepthCameraParams& cp,
+                            const vh::mat4f& lastRigidTransform)
+{
+    m_params.m_numOccupiedSDFBlocks = hashParams.m_numOccupiedBlocks;
+    const vh::mat4f view = lastRigidTransform.getInverse();
+    std::memcpy(m_params.m_viewMatrix, view.m, sizeof(view.m));
+    std::memcpy(m_params.m_viewMatrixInverse, lastRigidTransform.m, sizeof(lastRigidTransform.m));
+
+    if (m_timer) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream);
+    check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
+    if (m_timer) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
+    if (!m_params.m_useGradients) {
+        if (m_timer) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
+        check(vh_compute_normals(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, m_stream), "computeNormals");
+        if (m_timer) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
+    }
+}

@@ -1,0 +1,913 @@
+// vh_kernels.hip -- hand-written gfx950 kernels of the voxel-hash TSDF frame
+// loop and their launcher-level C ABI (include/vh_api.h).
+//
+// Reference behaviour: DSC/CUDASceneRepHashSDF.cu, DSC/CUDARayCastSDF.cu,
+// DSC/RayCastSDFUtil.h, DSC/CameraUtil.cu:669-711, DSC/CUDASceneRepChunkGrid.cu
+// (DSC/ = /root/reference/DepthSensingCUDA/Source/).  Nothing here is derived
+// from those kernels' structure: launch shapes, data movement and intra-wave
+// cooperation are designed for CDNA4 (wave64, 16-byte lanes, no textures, no
+// __constant__ singletons, no host round trips).
+//
+// MUST be compiled with -ffp-contract=off (see vh_device.hpp).
+#include <hip/hip_runtime.h>
+
+#include "../../include/vh_api.h"
+#include "vh_device.hpp"
+#include "vh_host_util.hpp"
+
+using namespace vhd;
+
+namespace {
+
+constexpr int kWave = 64;
+
+VHD uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
+VHD uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// ---------------------------------------------------------------------------
+// reset (resetHeapKernel / resetHashKernel / resetHashBucketMutexKernel,
+// DSC/CUDASceneRepHashSDF.cu:23-61).  Voxels and summaries are cleared with
+// hipMemsetAsync; these kernels write the non-zero patterns, 16 B per lane.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_reset_heap(uint32_t* heap, uint32_t* heapCounter, uint32_t n)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) heapCounter[0] = n - 1;
+    if (idx < n) heap[idx] = n - idx - 1;
+}
+
+__global__ __launch_bounds__(256) void k_reset_hash(VhHashEntry* a, VhHashEntry* b, uint32_t ne)
+{
+    // one 16-byte half-entry per lane: even lanes {0,0,0,FREE}, odd lanes {offset=0,pad}
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 2ull * ne) {
+        const int4 v = (idx & 1) ? make_int4(0, 0, 0, 0) : make_int4(0, 0, 0, VH_FREE_ENTRY);
+        reinterpret_cast<int4*>(a)[idx] = v;
+        reinterpret_cast<int4*>(b)[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t* p, int32_t v, uint32_t n)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) p[idx] = v;
+}
+
+// ---------------------------------------------------------------------------
+// alloc (allocKernel, DSC/CUDASceneRepHashSDF.cu:158-243)
+//
+// One wave per 8x8 pixel tile.  Each lane walks its ray's SDF blocks with the
+// reference's DDA; at every step the wave de-duplicates the block ids its
+// lanes ask for (neighbouring rays hit the same 8^3 block) and ONE lane probes
+// the table per distinct id, so the table sees ~1/64 of the reference's probes.
+// ---------------------------------------------------------------------------
+
+// worldToChunks :133-146, linearizeChunkPos :124-130, isSDFBlockStreamedOut :149-156
+VHD bool block_streamed_out(const VhHashParams& hp, I3 blk, const uint32_t* bitMask)
+{
+    if (!bitMask) return false;
+    F3 pw = block_to_world(hp.m_virtualVoxelSize, blk);
+    F3 p = mk3(pw.x / hp.m_streamingVoxelExtents[0], pw.y / hp.m_streamingVoxelExtents[1], pw.z / hp.m_streamingVoxelExtents[2]);
+    I3 c = mki3(f2i(p.x + (float)signi(p.x) * 0.5f), f2i(p.y + (float)signi(p.y) * 0.5f), f2i(p.z + (float)signi(p.z) * 0.5f));
+    I3 q = mki3(c.x - hp.m_streamingMinGridPos[0], c.y - hp.m_streamingMinGridPos[1], c.z - hp.m_streamingMinGridPos[2]);
+    uint32_t index = (uint32_t)(q.z * hp.m_streamingGridDimensions[0] * hp.m_streamingGridDimensions[1] +
+                                q.y * hp.m_streamingGridDimensions[0] + q.x);
+    return (bitMask[index >> 5] & (1u << (index & 31))) != 0u;
+}
+
+__global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
+                                               VhDepthCameraParams cp, const uint32_t* bitMask, int32_t lockToken)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t W = cp.m_imageWidth, H = cp.m_imageHeight;
+    const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
+    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (tile >= tilesX * tilesY) return; // wave-uniform
+    const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    const float vs = hp.m_virtualVoxelSize;
+
+    bool active = (x < W) && (y < H);
+    float d = active ? cam.d_depthData[y * W + x] : minf();
+    if (d == minf() || d == 0.0f) active = false;
+    if (d >= hp.m_maxIntegrationDistance) active = false;
+
+    const float t = get_truncation(hp, d);
+    const float minDepth = fminf(hp.m_maxIntegrationDistance, d - t);
+    const float maxDepth = fminf(hp.m_maxIntegrationDistance, d + t);
+    if (minDepth >= maxDepth) active = false;
+
+    const F3 rayMin = mat_mul_p(hp.m_rigidTransform, depth_to_skeleton(cp, x, y, minDepth));
+    const F3 rayMax = mat_mul_p(hp.m_rigidTransform, depth_to_skeleton(cp, x, y, maxDepth));
+    const F3 rayDir = normalize3(mk3(rayMax.x - rayMin.x, rayMax.y - rayMin.y, rayMax.z - rayMin.z));
+
+    I3 id = world_to_block(vs, rayMin);
+    const I3 idEnd = world_to_block(vs, rayMax);
+
+    const F3 step = mk3((float)signi(rayDir.x), (float)signi(rayDir.y), (float)signi(rayDir.z));
+    const I3 cl = mki3(f2i(fmaxf(0.0f, fminf(step.x, 1.0f))), f2i(fmaxf(0.0f, fminf(step.y, 1.0f))), f2i(fmaxf(0.0f, fminf(step.z, 1.0f))));
+    F3 boundaryPos = block_to_world(vs, mki3(id.x + cl.x, id.y + cl.y, id.z + cl.z));
+    const float half = 0.5f * vs;
+    boundaryPos.x -= half; boundaryPos.y -= half; boundaryPos.z -= half;
+    F3 tMax = mk3((boundaryPos.x - rayMin.x) / rayDir.x, (boundaryPos.y - rayMin.y) / rayDir.y, (boundaryPos.z - rayMin.z) / rayDir.z);
+    F3 tDelta = mk3((step.x * (float)VH_SDF_BLOCK_SIZE * vs) / rayDir.x, (step.y * (float)VH_SDF_BLOCK_SIZE * vs) / rayDir.y,
+                    (step.z * (float)VH_SDF_BLOCK_SIZE * vs) / rayDir.z);
+    const I3 idBound = mki3(f2i((float)idEnd.x + step.x), f2i((float)idEnd.y + step.y), f2i((float)idEnd.z + step.z));
+
+    if (rayDir.x == 0.0f) { tMax.x = pinf(); tDelta.x = pinf(); }
+    if (boundaryPos.x - rayMin.x == 0.0f) { tMax.x = pinf(); tDelta.x = pinf(); }
+    if (rayDir.y == 0.0f) { tMax.y = pinf(); tDelta.y = pinf(); }
+    if (boundaryPos.y - rayMin.y == 0.0f) { tMax.y = pinf(); tDelta.y = pinf(); }
+    if (rayDir.z == 0.0f) { tMax.z = pinf(); tDelta.z = pinf(); }
+    if (boundaryPos.z - rayMin.z == 0.0f) { tMax.z = pinf(); tDelta.z = pinf(); }
+
+    uint32_t iter = 0;
+    while (__any(active)) {
+        bool want = active && block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask);
+        // wave-level de-duplication of the requested block ids
+        uint64_t pending = __ballot(want);
+        while (pending) {
+            const int leader = __ffsll((unsigned long long)pending) - 1;
+            const int bx = __builtin_amdgcn_readlane(id.x, leader);
+            const int by = __builtin_amdgcn_readlane(id.y, leader);
+            const int bz = __builtin_amdgcn_readlane(id.z, leader);
+            const bool same = want && id.x == bx && id.y == by && id.z == bz;
+            pending &= ~__ballot(same);
+            if ((int)lane == leader) alloc_block(hd, hp, mki3(bx, by, bz), lockToken);
+        }
+        if (active) {
+            if (tMax.x < tMax.y && tMax.x < tMax.z) {
+                id.x = f2i((float)id.x + step.x);
+                if (id.x == idBound.x) active = false;
+                tMax.x += tDelta.x;
+            } else if (tMax.z < tMax.y) {
+                id.z = f2i((float)id.z + step.z);
+                if (id.z == idBound.z) active = false;
+                tMax.z += tDelta.z;
+            } else {
+                id.y = f2i((float)id.y + step.y);
+                if (id.y == idBound.y) active = false;
+                tMax.y += tDelta.y;
+            }
+            iter++;
+            if (iter >= 1024u) active = false;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// compactify (compactifyHashAllInOneKernel, DSC/CUDASceneRepHashSDF.cu:317-359)
+//
+// The reference scans all Ne entries (32 B each) every frame.  Here the
+// 1-bit-per-bucket summary is scanned instead (Nb/8 bytes) and only non-empty
+// buckets are opened; kept entries are packed with wave64 ballot + popcount
+// prefix and ONE atomic per wave.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp)
+{
+    const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
+    const uint32_t wordIdx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bits = (wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
+    while (__any(bits != 0u)) {
+        const bool has = bits != 0u;
+        const uint32_t bit = has ? (uint32_t)(__ffs((int)bits) - 1) : 0u;
+        const uint32_t bucket = wordIdx * 32u + bit;
+        bits &= bits - 1u;
+        const VhHashEntry* e = &hd.d_hash[(uint64_t)bucket * VH_HASH_BUCKET_SIZE];
+#pragma unroll 1
+        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
+            int4 q = make_int4(0, 0, 0, VH_FREE_ENTRY);
+            uint32_t off = 0;
+            if (has) { q = load_quad(&e[j]); off = e[j].offset; }
+            const bool keep = has && q.w != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(q.x, q.y, q.z));
+            const uint64_t m = __ballot(keep);
+            if (m) {
+                uint32_t base = 0;
+                if (lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1))
+                    base = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)__popcll(m));
+                base = __builtin_amdgcn_readlane(base, __ffsll((unsigned long long)m) - 1);
+                if (keep) {
+                    VhHashEntry* o = &hd.d_hashCompactified[base + (uint32_t)__popcll(m & lanemask_lt())];
+                    o->offset = off;
+                    store_quad(o, q);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// integrate / starve / garbage collection
+// (integrateDepthMapKernel :412-492, starveVoxelsKernel :512-521,
+//  garbageCollectIdentifyKernel :543-590, garbageCollectFreeKernel :608-628)
+//
+// One 256-thread workgroup per SDF block, two x-adjacent voxels (16 B) per
+// lane: a block is 4 waves x 1 KiB fully coalesced.  The fused kernel keeps the
+// block in registers across integrate -> starve -> identify -> free, so every
+// voxel is read once and written once per frame; min/max are reduced with
+// wave64 shuffles and a 4-entry LDS combine.
+// ---------------------------------------------------------------------------
+
+VHD Vox integrate_voxel(const VhHashParams& hp, const VhDepthCameraParams& cp, const VhDepthCameraData& cam, I3 pi, Vox stored)
+{
+    F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pi));
+    // cameraToKinectScreenInt, DSC/DepthCameraUtil.h:74-85 -> uint2
+    const uint32_t sx = (uint32_t)f2i((pf.x * cp.fx / pf.z + cp.mx) + 0.5f);
+    const uint32_t sy = (uint32_t)f2i((pf.y * cp.fy / pf.z + cp.my) + 0.5f);
+    if (sx < cp.m_imageWidth && sy < cp.m_imageHeight) {
+        const uint32_t pix = sy * cp.m_imageWidth + sx;
+        const float depth = cam.d_depthData[pix];
+        float cr = minf(), cg = minf(), cb = minf();
+        if (cam.d_colorData) {
+            const float4 c = reinterpret_cast<const float4*>(cam.d_colorData)[pix];
+            cr = c.x; cg = c.y; cb = c.z;
+        }
+        if (cr != minf() && depth != minf()) {
+            if (depth < hp.m_maxIntegrationDistance) {
+                const float depthZeroOne = cam_to_proj_z(cp, depth);
+                float sdf = depth - pf.z;
+                const float truncation = get_truncation(hp, depth);
+                if (sdf > -truncation) {
+                    if (sdf >= 0.0f) sdf = fminf(truncation, sdf);
+                    else sdf = fmaxf(-truncation, sdf);
+                    const float weightUpdate = fmaxf((float)hp.m_integrationWeightSample * 1.5f * (1.0f - depthZeroOne), 1.0f);
+                    Vox curr;
+                    curr.sdf = sdf;
+                    if (cam.d_colorData) curr.cw = pack_cw(f2uc(255.0f * cr), f2uc(255.0f * cg), f2uc(255.0f * cb), f2uc(weightUpdate));
+                    else curr.cw = pack_cw(0, 255, 0, f2uc(weightUpdate));
+                    return combine_voxel(hp, stored, curr);
+                }
+            }
+        }
+    }
+    return stored;
+}
+
+VHD Vox starve_voxel(Vox v)
+{
+    uint32_t w = v.weight();
+    w = (w > 0u) ? w - 1u : 0u;
+    v.cw = (v.cw & 0x00ffffffu) | (w << 24);
+    return v;
+}
+
+// block-wide min(|sdf| of weighted voxels) / max(weight): wave shuffle tree,
+// then one LDS slot per wave.  Every lane returns the block result.
+VHD void block_min_max(float& minSdf, uint32_t& maxW, float* sMin, uint32_t* sMax)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        minSdf = fminf(minSdf, __shfl_xor(minSdf, o));
+        maxW = max(maxW, (uint32_t)__shfl_xor((int)maxW, o));
+    }
+    const uint32_t wave = threadIdx.x / kWave;
+    if (lane_id() == 0) { sMin[wave] = minSdf; sMax[wave] = maxW; }
+    __syncthreads();
+    float m = sMin[0];
+    uint32_t w = sMax[0];
+    for (uint32_t i = 1; i < blockDim.x / kWave; i++) { m = fminf(m, sMin[i]); w = max(w, sMax[i]); }
+    minSdf = m; maxW = w;
+}
+
+VHD float gc_key(Vox v) { return (v.weight() == 0u) ? pinf() : fabsf(v.sdf); }
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_integrate(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
+                                                   VhDepthCameraParams cp, uint32_t flags, int32_t lockToken)
+{
+    __shared__ float sMin[4];
+    __shared__ uint32_t sMax[4];
+    __shared__ int sFreed;
+
+    const uint32_t count = FUSED ? (uint32_t)hd.d_hashCompactifiedCounter[0] : hp.m_numOccupiedBlocks;
+    const uint32_t t = threadIdx.x;
+    // voxel pair (2t, 2t+1): x = (2t)%8 (+1), y = (2t%64)/8, z = 2t/64  (delinearizeVoxelIndex, DSC/VoxelUtilHashSDF.h:313-318)
+    const int lx = (int)((2u * t) & 7u), ly = (int)(((2u * t) & 63u) >> 3), lz = (int)((2u * t) >> 6);
+
+    for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
+        const int4 q = load_quad(&hd.d_hashCompactified[b]);
+        const int ex = __builtin_amdgcn_readfirstlane(q.x), ey = __builtin_amdgcn_readfirstlane(q.y);
+        const int ez = __builtin_amdgcn_readfirstlane(q.z), ptr = __builtin_amdgcn_readfirstlane(q.w);
+
+        uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + t;
+        const uint4 raw = *vp;
+        Vox v0 = unpack_vox(make_uint2(raw.x, raw.y)), v1 = unpack_vox(make_uint2(raw.z, raw.w));
+
+        const I3 p0 = mki3(ex * VH_SDF_BLOCK_SIZE + lx, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + lz);
+        v0 = integrate_voxel(hp, cp, cam, p0, v0);
+        v1 = integrate_voxel(hp, cp, cam, mki3(p0.x + 1, p0.y, p0.z), v1);
+        // Pin the four result words in VGPRs here.  Without this, hipcc (ROCm 7.2, gfx950, -O3) merges the
+        // "not integrated" path of the second voxel with a register that the colour fetch has already
+        // overwritten (found by the parity tests: sdf of skipped odd voxels came back as the colour's MINF).
+        asm volatile("" : "+v"(v0.sdf), "+v"(v0.cw), "+v"(v1.sdf), "+v"(v1.cw));
+
+        bool freed = false;
+        if (FUSED && (flags & VH_FUSED_GC)) {
+            if (flags & VH_FUSED_STARVE) { v0 = starve_voxel(v0); v1 = starve_voxel(v1); }
+            float minSdf = fminf(gc_key(v0), gc_key(v1));
+            uint32_t maxW = max(v0.weight(), v1.weight());
+            __syncthreads(); // LDS slots of the previous block iteration are consumed
+            block_min_max(minSdf, maxW, sMin, sMax);
+            const float thr = get_truncation(hp, cp.m_sensorDepthWorldMax);
+            const bool decide = (minSdf >= thr) || (maxW == 0u);
+            if (t == 0) {
+                hd.d_hashDecision[b] = decide ? 1 : 0;
+                sFreed = (decide && delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), lockToken)) ? 1 : 0;
+            }
+            __syncthreads();
+            freed = sFreed != 0;
+        }
+        if (freed) {
+            *vp = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            const uint2 a = pack_vox(v0), c = pack_vox(v1);
+            *vp = make_uint4(a.x, a.y, c.x, c.y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_starve(VhHashData hd, VhHashParams hp)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= hp.m_numOccupiedBlocks) return;
+    const int ptr = __builtin_amdgcn_readfirstlane(load_quad(&hd.d_hashCompactified[b]).w);
+    uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + threadIdx.x;
+    uint4 raw = *vp;
+    Vox v0 = starve_voxel(unpack_vox(make_uint2(raw.x, raw.y))), v1 = starve_voxel(unpack_vox(make_uint2(raw.z, raw.w)));
+    raw.y = v0.cw; raw.w = v1.cw;
+    *vp = raw;
+}
+
+__global__ __launch_bounds__(256) void k_gc_identify(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp)
+{
+    __shared__ float sMin[4];
+    __shared__ uint32_t sMax[4];
+    const uint32_t b = blockIdx.x;
+    if (b >= hp.m_numOccupiedBlocks) return;
+    const int ptr = __builtin_amdgcn_readfirstlane(load_quad(&hd.d_hashCompactified[b]).w);
+    const uint4 raw = *(reinterpret_cast<const uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + threadIdx.x);
+    const Vox v0 = unpack_vox(make_uint2(raw.x, raw.y)), v1 = unpack_vox(make_uint2(raw.z, raw.w));
+    float minSdf = fminf(gc_key(v0), gc_key(v1));
+    uint32_t maxW = max(v0.weight(), v1.weight());
+    block_min_max(minSdf, maxW, sMin, sMax);
+    if (threadIdx.x == 0) {
+        const float thr = get_truncation(hp, cp.m_sensorDepthWorldMax);
+        hd.d_hashDecision[b] = ((minSdf >= thr) || (maxW == 0u)) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gc_free(VhHashData hd, VhHashParams hp, int32_t lockToken)
+{
+    __shared__ int sFreed;
+    const uint32_t b = blockIdx.x;
+    if (b >= hp.m_numOccupiedBlocks) return;
+    if (hd.d_hashDecision[b] == 0) return; // block-uniform
+    const int4 q = load_quad(&hd.d_hashCompactified[b]);
+    if (threadIdx.x == 0) sFreed = delete_hash_entry_element(hd, hp, mki3(q.x, q.y, q.z), lockToken) ? 1 : 0;
+    __syncthreads();
+    if (sFreed) {
+        const int ptr = __builtin_amdgcn_readfirstlane(q.w);
+        *(reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + threadIdx.x) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ray caster (renderKernel DSC/CUDARayCastSDF.cu:18-57,
+// traverseCoarseGridSimpleSampleAll DSC/RayCastSDFUtil.h:198-262)
+//
+// One wave per 8x8 pixel tile (rays of a tile stay in the same few blocks).
+// Per ray: a one-entry block cache (block id -> ptr) so the 8 taps of a
+// sample and consecutive samples re-probe the table only when they change
+// block, and the bucket-occupancy bit turns a probe of empty space into a
+// single cached dword test.  Every arithmetic step, its order and every
+// early-out is the reference's.
+// ---------------------------------------------------------------------------
+
+struct BlockCache {
+    int bx, by, bz, ptr;
+    bool valid;
+};
+
+VHD bool fetch_voxel(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, int vx, int vy, int vz, Vox& v)
+{
+    const int bx = vvp_to_block1(vx), by = vvp_to_block1(vy), bz = vvp_to_block1(vz);
+    if (!(bc.valid && bc.bx == bx && bc.by == by && bc.bz == bz)) {
+        bc.ptr = lookup_ptr(hd, hp, mki3(bx, by, bz));
+        bc.bx = bx; bc.by = by; bc.bz = bz; bc.valid = true;
+    }
+    if (bc.ptr == VH_FREE_ENTRY) return false; // getVoxel returns the zero voxel: weight 0
+    const uint2 w = *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)bc.ptr + (uint32_t)vvp_to_local_index(mki3(vx, vy, vz))]);
+    v = unpack_vox(w);
+    return v.weight() != 0u;
+}
+
+// trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116
+VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 pos, float& dist, uint32_t& colorOut)
+{
+    const float vs = hp.m_virtualVoxelSize;
+    const float oSet = vs;
+    const float h = oSet / 2.0f;
+    const F3 pd = mk3(pos.x - h, pos.y - h, pos.z - h);
+    const float fx = pos.x / vs, fy = pos.y / vs, fz = pos.z / vs;
+    const float wx = fx - floorf(fx), wy = fy - floorf(fy), wz = fz - floorf(fz);
+
+    const int x0 = world_to_vvp1(pd.x, vs), x1 = world_to_vvp1(pd.x + oSet, vs);
+    const int y0 = world_to_vvp1(pd.y, vs), y1 = world_to_vvp1(pd.y + oSet, vs);
+    const int z0 = world_to_vvp1(pd.z, vs), z1 = world_to_vvp1(pd.z + oSet, vs);
+
+    float d = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    Vox v;
+#define VH_TAP(VX, VY, VZ, WX, WY, WZ)                                  \
+    if (!fetch_voxel(hd, hp, bc, VX, VY, VZ, v)) { dist = d; return false; } \
+    {                                                                   \
+        const float s = (WX) * (WY) * (WZ);                             \
+        d += s * v.sdf;                                                 \
+        cr += s * (float)v.r(); cg += s * (float)v.g(); cb += s * (float)v.b(); \
+    }
+    VH_TAP(x0, y0, z0, 1.0f - wx, 1.0f - wy, 1.0f - wz)
+    VH_TAP(x1, y0, z0, wx, 1.0f - wy, 1.0f - wz)
+    VH_TAP(x0, y1, z0, 1.0f - wx, wy, 1.0f - wz)
+    VH_TAP(x0, y0, z1, 1.0f - wx, 1.0f - wy, wz)
+    VH_TAP(x1, y1, z0, wx, wy, 1.0f - wz)
+    VH_TAP(x0, y1, z1, 1.0f - wx, wy, wz)
+    VH_TAP(x1, y0, z1, wx, 1.0f - wy, wz)
+    VH_TAP(x1, y1, z1, wx, wy, wz)
+#undef VH_TAP
+    dist = d;
+    colorOut = (uint32_t)f2uc(cr) | ((uint32_t)f2uc(cg) << 8) | ((uint32_t)f2uc(cb) << 16);
+    return true;
+}
+
+// findIntersectionBisection :149-170 over findIntersectionLinear :140-143
+VHD bool intersect_bisection(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 camPos, F3 dir,
+                             float d0, float r0, float d1, float r1, float& alpha, uint32_t& color)
+{
+    float a = r0, aDist = d0, b = r1, bDist = d1, c = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+        c = a + (aDist / (aDist - bDist)) * (b - a);
+        float cDist;
+        if (!trilinear(hd, hp, bc, mk3(camPos.x + c * dir.x, camPos.y + c * dir.y, camPos.z + c * dir.z), cDist, color)) return false;
+        if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
+        else { b = c; bDist = cDist; }
+    }
+    alpha = c;
+    return true;
+}
+
+// gradientForPoint :174-195
+VHD F3 gradient_for_point(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 pos)
+{
+    const float vs = hp.m_virtualVoxelSize;
+    float dp00 = 0.0f, d0p0 = 0.0f, d00p = 0.0f, d100 = 0.0f, d010 = 0.0f, d001 = 0.0f;
+    uint32_t c;
+    trilinear(hd, hp, bc, mk3(pos.x - 0.5f * vs, pos.y - 0.0f, pos.z - 0.0f), dp00, c);
+    trilinear(hd, hp, bc, mk3(pos.x - 0.0f, pos.y - 0.5f * vs, pos.z - 0.0f), d0p0, c);
+    trilinear(hd, hp, bc, mk3(pos.x - 0.0f, pos.y - 0.0f, pos.z - 0.5f * vs), d00p, c);
+    trilinear(hd, hp, bc, mk3(pos.x + 0.5f * vs, pos.y + 0.0f, pos.z + 0.0f), d100, c);
+    trilinear(hd, hp, bc, mk3(pos.x + 0.0f, pos.y + 0.5f * vs, pos.z + 0.0f), d010, c);
+    trilinear(hd, hp, bc, mk3(pos.x + 0.0f, pos.y + 0.0f, pos.z + 0.5f * vs), d001, c);
+    const F3 g = mk3((dp00 - d100) / vs, (d0p0 - d010) / vs, (d00p - d001) / vs);
+    const float l = sqrtf(dot3(g, g));
+    if (l == 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    return mk3(-g.x / l, -g.y / l, -g.z / l);
+}
+
+__global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd,
+                                                VhDepthCameraParams cp, VhRayCastParams rp)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t W = rp.m_width, H = rp.m_height;
+    const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
+    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (tile >= tilesX * tilesY) return;
+    const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x >= W || y >= H) return;
+    const size_t pix = (size_t)y * W + x;
+
+    const float mi = minf();
+    float outDepth = mi;
+    float4 outDepth4 = make_float4(mi, mi, mi, mi), outNormal = outDepth4, outColor = outDepth4;
+
+    const F3 camDir = normalize3(depth_to_skeleton(cp, x, y, proj_to_cam_z(cp, 1.0f)));
+    const F3 worldCamPos = mat_mul_p(rp.m_viewMatrixInverse, mk3(0.0f, 0.0f, 0.0f));
+    const F3 worldDir = normalize3(mat_mul_d(rp.m_viewMatrixInverse, camDir));
+
+    const float minInterval = rp.m_minDepth, maxInterval = rp.m_maxDepth;
+    const bool run = !(minInterval == 0.0f || minInterval == mi) && !(maxInterval == 0.0f || maxInterval == mi);
+    if (run) {
+        float lastSdf = 0.0f, lastAlpha = 0.0f;
+        bool lastValid = false;
+        const float depthToRayLength = 1.0f / camDir.z;
+        float rayCurrent = depthToRayLength * fmaxf(rp.m_minDepth, minInterval);
+        const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
+        BlockCache bc;
+        bc.valid = false; bc.bx = bc.by = bc.bz = 0; bc.ptr = VH_FREE_ENTRY;
+
+#pragma unroll 1
+        while (rayCurrent < rayEnd) {
+            const F3 p = mk3(worldCamPos.x + rayCurrent * worldDir.x, worldCamPos.y + rayCurrent * worldDir.y, worldCamPos.z + rayCurrent * worldDir.z);
+            float dist;
+            uint32_t color;
+            if (trilinear(hd, hp, bc, p, dist, color)) {
+                if (lastValid && lastSdf > 0.0f && dist < 0.0f) {
+                    float alpha = 0.0f;
+                    uint32_t color2 = 0;
+                    const bool ok = intersect_bisection(hd, hp, bc, worldCamPos, worldDir, lastSdf, lastAlpha, dist, rayCurrent, alpha, color2);
+                    if (ok && fabsf(lastSdf - dist) < rp.m_thresSampleDist) {
+                        if (fabsf(dist) < rp.m_thresDist) {
+                            const float depth = alpha / depthToRayLength;
+                            outDepth = depth;
+                            const F3 sk = depth_to_skeleton(cp, x, y, depth);
+                            outDepth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
+                            outColor = make_float4((float)(color2 & 0xffu) / 255.f, (float)((color2 >> 8) & 0xffu) / 255.f,
+                                                   (float)((color2 >> 16) & 0xffu) / 255.f, 1.0f);
+                            if (rp.m_useGradients) {
+                                const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
+                                const F3 g = gradient_for_point(hd, hp, bc, iso);
+                                const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
+                                outNormal = make_float4(n.x, n.y, n.z, 1.0f);
+                            }
+                            break;
+                        }
+                    }
+                }
+                lastSdf = dist;
+                lastAlpha = rayCurrent;
+                lastValid = true;
+            } else {
+                lastValid = false;
+            }
+            rayCurrent += rp.m_rayIncrement;
+        }
+    }
+    rd.d_depth[pix] = outDepth;
+    reinterpret_cast<float4*>(rd.d_depth4)[pix] = outDepth4;
+    reinterpret_cast<float4*>(rd.d_normals)[pix] = outNormal;
+    reinterpret_cast<float4*>(rd.d_colors)[pix] = outColor;
+}
+
+// computeNormalsDevice, DSC/CameraUtil.cu:669-697
+__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= width * height) return;
+    const uint32_t x = idx % width, y = idx / width;
+    const float mi = minf();
+    float4 o = make_float4(mi, mi, mi, mi);
+    if (x > 0 && x < width - 1 && y > 0 && y < height - 1) {
+        const float4 CC = in[idx], PC = in[idx + width], CP = in[idx + 1], MC = in[idx - width], CM = in[idx - 1];
+        if (CC.x != mi && PC.x != mi && CP.x != mi && MC.x != mi && CM.x != mi) {
+            const F3 a = mk3(PC.x - MC.x, PC.y - MC.y, PC.z - MC.z), b = mk3(CP.x - CM.x, CP.y - CM.y, CP.z - CM.z);
+            const F3 n = mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+            const float l = sqrtf(dot3(n, n));
+            if (l > 0.0f) o = make_float4(n.x / -l, n.y / -l, n.z / -l, 1.0f);
+        }
+    }
+    out[idx] = o;
+}
+
+// ---------------------------------------------------------------------------
+// streaming (DSC/CUDASceneRepChunkGrid.cu)
+// ---------------------------------------------------------------------------
+
+// integrateFromGlobalHashPass1Kernel :27-74.  The double heap push of the
+// reference's list branch (:58-64) is not reproduced: the element delete is
+// the only push (DESIGN.md "Fenced reference defects").
+__global__ __launch_bounds__(64) void k_stream_out_pass1(VhHashData hd, VhHashParams hp, uint32_t start, float radius,
+                                                         float cx, float cy, float cz, uint32_t* outCounter,
+                                                         VhSDFBlockDesc* out, uint32_t capacity, int32_t lockToken)
+{
+    const uint32_t ne = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x + start;
+    if (idx >= ne) return;
+    VhHashEntry* e = &hd.d_hash[idx];
+    const int4 q = load_quad(e);
+    const uint32_t off = e->offset;
+    const I3 pos = mki3(q.x, q.y, q.z);
+    const F3 pw = block_to_world(hp.m_virtualVoxelSize, pos);
+    const F3 df = mk3(pw.x - cx, pw.y - cy, pw.z - cz);
+    const float d = sqrtf(dot3(df, df));
+    if (q.w != VH_FREE_ENTRY && d >= radius) {
+        bool emit = false;
+        if (off != 0u || hash_pos(hp.m_hashNumBuckets, pos) != idx / VH_HASH_BUCKET_SIZE) {
+            emit = delete_hash_entry_element(hd, hp, pos, lockToken);
+        } else {
+            append_heap(hd, (uint32_t)q.w / VH_SDF_BLOCK_VOXELS);
+            delete_hash_entry(e);
+            bucket_dec(hd, idx);
+            emit = true;
+        }
+        if (emit) {
+            const uint32_t addr = atomicAdd(outCounter, 1u);
+            if (addr < capacity) {
+                VhSDFBlockDesc dsc;
+                dsc.pos[0] = q.x; dsc.pos[1] = q.y; dsc.pos[2] = q.z; dsc.ptr = q.w;
+                out[addr] = dsc;
+            }
+        }
+    }
+}
+
+// integrateFromGlobalHashPass2Kernel :97-113 (copy block out, clear source)
+__global__ __launch_bounds__(256) void k_stream_out_pass2(VhHashData hd, const VhSDFBlockDesc* descs, VhVoxel* out, uint32_t n)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const int ptr = __builtin_amdgcn_readfirstlane(descs[b].ptr);
+    uint4* src = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + threadIdx.x;
+    reinterpret_cast<uint4*>(out)[(size_t)b * 256 + threadIdx.x] = *src;
+    *src = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// chunkToGlobalHashPass1Kernel :143-160
+__global__ __launch_bounds__(64) void k_stream_in_pass1(VhHashData hd, VhHashParams hp, uint32_t n, uint32_t heapCountPrev,
+                                                        const VhSDFBlockDesc* descs, int32_t lockToken)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ptr = hd.d_heap[heapCountPrev - i] * VH_SDF_BLOCK_VOXELS;
+    const VhSDFBlockDesc dsc = descs[i];
+    if (!insert_hash_entry(hd, hp, mki3(dsc.pos[0], dsc.pos[1], dsc.pos[2]), (int)ptr, lockToken))
+        atomicAdd(&hd.d_state[VH_STATE_INSERT_FAILED], 1u);
+}
+
+// chunkToGlobalHashPass2Kernel :181-189
+__global__ __launch_bounds__(256) void k_stream_in_pass2(VhHashData hd, uint32_t n, uint32_t heapCountPrev, const VhVoxel* blocks)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const uint32_t ptr = hd.d_heap[heapCountPrev - b] * VH_SDF_BLOCK_VOXELS;
+    *(reinterpret_cast<uint4*>(&hd.d_SDFBlocks[ptr]) + threadIdx.x) = reinterpret_cast<const uint4*>(blocks)[(size_t)b * 256 + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// utilities
+// ---------------------------------------------------------------------------
+
+struct SynthArgs {
+    double spheres[4 * 8];
+    int nSpheres;
+    int inside;
+    float T[16];
+};
+
+// analytic sphere scene in double, rounded once to float
+__global__ __launch_bounds__(256) void k_synth(SynthArgs a, VhDepthCameraParams cp, float* depth, float4* color)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cp.m_imageWidth * cp.m_imageHeight) return;
+    const uint32_t u = idx % cp.m_imageWidth, v = idx / cp.m_imageWidth;
+    const double ox = (double)a.T[3], oy = (double)a.T[7], oz = (double)a.T[11];
+    const double dx = ((double)u - (double)cp.mx) / (double)cp.fx;
+    const double dy = ((double)v - (double)cp.my) / (double)cp.fy;
+    const double wx = (double)a.T[0] * dx + (double)a.T[1] * dy + (double)a.T[2];
+    const double wy = (double)a.T[4] * dx + (double)a.T[5] * dy + (double)a.T[6];
+    const double wz = (double)a.T[8] * dx + (double)a.T[9] * dy + (double)a.T[10];
+    const double aa = wx * wx + wy * wy + wz * wz;
+    double bestT = 0.0;
+    int best = -1;
+    for (int s = 0; s < a.nSpheres; s++) {
+        const double cx = a.spheres[4 * s + 0], cy = a.spheres[4 * s + 1], cz = a.spheres[4 * s + 2], r = a.spheres[4 * s + 3];
+        const double ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+        const double b = ocx * wx + ocy * wy + ocz * wz;
+        const double c = ocx * ocx + ocy * ocy + ocz * ocz - r * r;
+        const double disc = b * b - aa * c;
+        if (disc < 0.0) continue;
+        const double sq = sqrt(disc);
+        const double t = a.inside ? (-b + sq) / aa : (-b - sq) / aa;
+        if (t > 0.0 && (best < 0 || t < bestT)) { bestT = t; best = s; }
+    }
+    const float mi = minf();
+    if (best < 0) {
+        depth[idx] = mi;
+        color[idx] = make_float4(mi, mi, mi, mi);
+    } else {
+        const double cx = a.spheres[4 * best + 0], cy = a.spheres[4 * best + 1], cz = a.spheres[4 * best + 2], r = a.spheres[4 * best + 3];
+        const double px = ox + bestT * wx, py = oy + bestT * wy, pz = oz + bestT * wz;
+        double nx = (px - cx) / r, ny = (py - cy) / r, nz = (pz - cz) / r;
+        if (a.inside) { nx = -nx; ny = -ny; nz = -nz; }
+        depth[idx] = (float)bestT;
+        color[idx] = make_float4((float)(0.5 + 0.5 * nx), (float)(0.5 + 0.5 * ny), (float)(0.5 + 0.5 * nz), 1.0f);
+    }
+}
+
+// serial hash-operation interpreter (tests of the collision paths)
+__global__ void k_debug_hash_ops(VhHashData hd, VhHashParams hp, const int32_t* ops, int32_t* results, uint32_t n)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int32_t token = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t op = ops[5 * i + 0];
+        const I3 p = mki3(ops[5 * i + 1], ops[5 * i + 2], ops[5 * i + 3]);
+        const int32_t arg = ops[5 * i + 4];
+        int32_t r = 0;
+        switch (op) {
+        case VH_OP_ALLOC: r = alloc_block(hd, hp, p, token); break;
+        case VH_OP_DELETE: r = delete_hash_entry_element(hd, hp, p, token) ? 1 : 0; break;
+        case VH_OP_INSERT: r = insert_hash_entry(hd, hp, p, arg, token) ? 1 : 0; break;
+        case VH_OP_LOOKUP: r = lookup_ptr(hd, hp, p); break;
+        case VH_OP_NEW_PASS: token++; break;
+        default: break;
+        }
+        results[i] = r;
+    }
+}
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// launcher-level C ABI
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+int vh_reset(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream)
+{
+    if (!hd || !hp || !hd->d_hash) return VH_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = hp->m_hashNumBuckets, ne = nb * VH_HASH_BUCKET_SIZE, nblk = hp->m_numSDFBlocks;
+    VH_HIP(hipMemsetAsync(hd->d_SDFBlocks, 0, sizeof(VhVoxel) * (size_t)nblk * VH_SDF_BLOCK_VOXELS, s));
+    VH_HIP(hipMemsetAsync(hd->d_bucketCount, 0, sizeof(uint32_t) * nb, s));
+    VH_HIP(hipMemsetAsync(hd->d_bucketBits, 0, sizeof(uint32_t) * ((nb + 31) / 32), s));
+    VH_HIP(hipMemsetAsync(hd->d_state, 0, sizeof(uint32_t) * VH_STATE_WORDS, s));
+    VH_HIP(hipMemsetAsync(hd->d_hashDecision, 0, sizeof(int32_t) * ne, s));
+    VH_HIP(hipMemsetAsync(hd->d_hashCompactifiedCounter, 0, sizeof(int32_t), s));
+    k_reset_heap<<<cdiv(nblk, 256), 256, 0, s>>>(hd->d_heap, hd->d_heapCounter, nblk);
+    k_reset_hash<<<cdiv(2ull * ne, 256), 256, 0, s>>>(hd->d_hash, hd->d_hashCompactified, ne);
+    k_fill_i32<<<cdiv(nb, 256), 256, 0, s>>>(hd->d_hashBucketMutex, VH_FREE_ENTRY, nb);
+    return vh_last_launch_error();
+}
+
+int vh_reset_bucket_mutex(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream)
+{
+    if (!hd || !hp) return VH_ERR_BAD_ARGUMENT;
+    k_fill_i32<<<cdiv(hp->m_hashNumBuckets, 256), 256, 0, (hipStream_t)stream>>>(hd->d_hashBucketMutex, VH_FREE_ENTRY, hp->m_hashNumBuckets);
+    return vh_last_launch_error();
+}
+
+int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+             const VhDepthCameraParams* cp, const uint32_t* d_bitMask, int32_t lockToken, vhStream_t stream)
+{
+    if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t tiles = cdiv(cp->m_imageWidth, 8) * cdiv(cp->m_imageHeight, 8);
+    if (tiles == 0) return VH_OK;
+    k_alloc<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken);
+    return vh_last_launch_error();
+}
+
+int vh_compactify(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp,
+                  uint32_t* numOccupied, vhStream_t stream)
+{
+    if (!hd || !hp || !cp) return VH_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    VH_HIP(hipMemsetAsync(hd->d_hashCompactifiedCounter, 0, sizeof(int32_t), s));
+    const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
+    k_compactify<<<cdiv(nWords, 256), 256, 0, s>>>(*hd, *hp, *cp);
+    int err = vh_last_launch_error();
+    if (err) return err;
+    if (numOccupied) {
+        VH_HIP(hipMemcpyAsync(numOccupied, hd->d_hashCompactifiedCounter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VH_HIP(hipStreamSynchronize(s));
+    }
+    return VH_OK;
+}
+
+int vh_integrate(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+                 const VhDepthCameraParams* cp, vhStream_t stream)
+{
+    if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
+    if (hp->m_numOccupiedBlocks == 0) return VH_OK; // DSC/CUDASceneRepHashSDF.cu:501
+    k_integrate<false><<<hp->m_numOccupiedBlocks, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, 0u, VH_LOCK_ENTRY);
+    return vh_last_launch_error();
+}
+
+int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, vhStream_t stream)
+{
+    if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
+    // persistent grid: the block count lives on the device, so no host read-back is needed
+    const uint32_t grid = hp->m_numSDFBlocks < 2048u ? hp->m_numSDFBlocks : 2048u;
+    k_integrate<true><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken);
+    return vh_last_launch_error();
+}
+
+int vh_starve(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream)
+{
+    if (!hd || !hp) return VH_ERR_BAD_ARGUMENT;
+    if (hp->m_numOccupiedBlocks == 0) return VH_OK;
+    k_starve<<<hp->m_numOccupiedBlocks, 256, 0, (hipStream_t)stream>>>(*hd, *hp);
+    return vh_last_launch_error();
+}
+
+int vh_gc_identify(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, vhStream_t stream)
+{
+    if (!hd || !hp || !cp) return VH_ERR_BAD_ARGUMENT;
+    if (hp->m_numOccupiedBlocks == 0) return VH_OK;
+    k_gc_identify<<<hp->m_numOccupiedBlocks, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp);
+    return vh_last_launch_error();
+}
+
+int vh_gc_free(const VhHashData* hd, const VhHashParams* hp, int32_t lockToken, vhStream_t stream)
+{
+    if (!hd || !hp) return VH_ERR_BAD_ARGUMENT;
+    if (hp->m_numOccupiedBlocks == 0) return VH_OK;
+    k_gc_free<<<hp->m_numOccupiedBlocks, 256, 0, (hipStream_t)stream>>>(*hd, *hp, lockToken);
+    return vh_last_launch_error();
+}
+
+int vh_bind_input_depth_color_textures(const VhDepthCameraData* cam)
+{
+    (void)cam;
+    return VH_OK;
+}
+
+int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd,
+              const VhDepthCameraParams* cp, const VhRayCastParams* rp, vhStream_t stream)
+{
+    if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
+    if (tiles == 0) return VH_OK;
+    k_render<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp);
+    return vh_last_launch_error();
+}
+
+int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output4 || !d_input4) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_compute_normals<<<cdiv((uint64_t)width * height, 256), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height);
+    return vh_last_launch_error();
+}
+
+int vh_stream_out_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start,
+                        float radius, const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_output,
+                        uint32_t outputCapacity, int32_t lockToken, vhStream_t stream)
+{
+    if (!hd || !hp || !camPos || !d_outputCounter || !d_output) return VH_ERR_BAD_ARGUMENT;
+    if (threadsPerPart == 0) return VH_OK; // DSC/CUDASceneRepChunkGrid.cu:81
+    k_stream_out_pass1<<<cdiv(threadsPerPart, 64), 64, 0, (hipStream_t)stream>>>(*hd, *hp, start, radius, camPos[0], camPos[1], camPos[2],
+                                                                                   d_outputCounter, d_output, outputCapacity, lockToken);
+    return vh_last_launch_error();
+}
+
+int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSDFBlockDesc* d_descs,
+                        VhVoxel* d_output, uint32_t nSDFBlocks, vhStream_t stream)
+{
+    (void)hp;
+    if (!hd || !d_descs || !d_output) return VH_ERR_BAD_ARGUMENT;
+    if (nSDFBlocks == 0) return VH_OK;
+    k_stream_out_pass2<<<nSDFBlocks, 256, 0, (hipStream_t)stream>>>(*hd, d_descs, d_output, nSDFBlocks);
+    return vh_last_launch_error();
+}
+
+int vh_stream_in_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                       const VhSDFBlockDesc* d_descs, int32_t lockToken, vhStream_t stream)
+{
+    if (!hd || !hp || !d_descs) return VH_ERR_BAD_ARGUMENT;
+    if (n == 0) return VH_OK;
+    if (n > heapCountPrev + 1u) return VH_ERR_HEAP_EXHAUSTED;
+    k_stream_in_pass1<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(*hd, *hp, n, heapCountPrev, d_descs, lockToken);
+    return vh_last_launch_error();
+}
+
+int vh_stream_in_pass2(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                       const VhSDFBlockDesc* d_descs, const VhVoxel* d_blocks, vhStream_t stream)
+{
+    (void)hp; (void)d_descs;
+    if (!hd || !d_blocks) return VH_ERR_BAD_ARGUMENT;
+    if (n == 0) return VH_OK;
+    if (n > heapCountPrev + 1u) return VH_ERR_HEAP_EXHAUSTED;
+    k_stream_in_pass2<<<n, 256, 0, (hipStream_t)stream>>>(*hd, n, heapCountPrev, d_blocks);
+    return vh_last_launch_error();
+}
+
+int vh_synth_frame(const double* h_spheres, int nSpheres, int inside, const float camToWorld[16],
+                   const VhDepthCameraParams* cp, float* d_depth, float* d_color4, vhStream_t stream)
+{
+    if (!h_spheres || !camToWorld || !cp || !d_depth || !d_color4 || nSpheres < 0 || nSpheres > 8) return VH_ERR_BAD_ARGUMENT;
+    SynthArgs a;
+    for (int i = 0; i < 4 * nSpheres; i++) a.spheres[i] = h_spheres[i];
+    a.nSpheres = nSpheres;
+    a.inside = inside;
+    for (int i = 0; i < 16; i++) a.T[i] = camToWorld[i];
+    const uint64_t n = (uint64_t)cp->m_imageWidth * cp->m_imageHeight;
+    if (n == 0) return VH_OK;
+    k_synth<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(a, *cp, d_depth, reinterpret_cast<float4*>(d_color4));
+    return vh_last_launch_error();
+}
+
+int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_t* d_ops, int32_t* d_results,
+                      uint32_t n, vhStream_t stream)
+{
+    if (!hd || !hp || !d_ops || !d_results) return VH_ERR_BAD_ARGUMENT;
+    if (n == 0) return VH_OK;
+    k_debug_hash_ops<<<1, 64, 0, (hipStream_t)stream>>>(*hd, *hp, d_ops, d_results, n);
+    return vh_last_launch_error();
+}
+
+} // extern "C"

@@ -1,0 +1,321 @@
+"""Python mirror of the reference host classes over the C ABI:
+
+    CUDASceneRepHashSDF   (DepthSensingCUDA/Source/CUDASceneRepHashSDF.h:28)
+    CUDARayCastSDF        (DepthSensingCUDA/Source/CUDARayCastSDF.h:13)
+    CUDASceneRepChunkGrid (DepthSensingCUDA/Source/CUDASceneRepChunkGrid.h:152)
+
+Same method names and argument meaning as the reference (camelCase kept), so
+tests read like the reference's frame loop (DepthSensing.cpp:720-924).  All
+compute happens in libvoxelhashing_amd.so on the GPU; this file only marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import canonical
+from . import vhtypes as T
+from .lib import DeviceBuffer, check, download, f16, load
+
+
+def _copy_struct(s):
+    out = type(s)()
+    C.memmove(C.byref(out), C.byref(s), C.sizeof(s))
+    return out
+
+
+class DepthFrame:
+    """Device-resident depth + colour image pair (DepthCameraData,
+    DepthSensingCUDA/Source/DepthCameraUtil.h:17)."""
+
+    def __init__(self, cam_params, depth=None, color=None, depth_ptr=None, color_ptr=None, stream=None):
+        self.cp = cam_params
+        n = cam_params.m_imageWidth * cam_params.m_imageHeight
+        self._own = []
+        if depth_ptr is None:
+            buf = DeviceBuffer(4 * n)
+            self._own.append(buf)
+            depth_ptr = buf.ptr
+            if depth is not None:
+                buf.upload(np.ascontiguousarray(depth, dtype=np.float32), stream)
+        if color_ptr is None and color is not False:
+            buf = DeviceBuffer(16 * n)
+            self._own.append(buf)
+            color_ptr = buf.ptr
+            if color is not None:
+                buf.upload(np.ascontiguousarray(color, dtype=np.float32), stream)
+        self.depth_ptr = depth_ptr
+        self.color_ptr = color_ptr if color is not False else None
+        self.data = T.DepthCameraData(self.depth_ptr, self.color_ptr)
+
+    def download(self):
+        H, W = self.cp.m_imageHeight, self.cp.m_imageWidth
+        d = download(self.depth_ptr, np.float32, H * W).reshape(H, W)
+        c = download(self.color_ptr, np.float32, H * W * 4).reshape(H, W, 4) if self.color_ptr else None
+        return d, c
+
+
+def synth_frame(spheres, inside, cam_to_world, cam_params, out=None, stream=None):
+    """generate a synthetic frame on the device (vh_synth_frame)"""
+    fr = out if out is not None else DepthFrame(cam_params)
+    sp = np.ascontiguousarray(spheres, dtype=np.float64)
+    check(load().vh_synth_frame(sp.ctypes.data, sp.shape[0], int(inside), f16(cam_to_world), C.byref(cam_params),
+                                fr.depth_ptr, fr.color_ptr, stream), "vh_synth_frame")
+    return fr
+
+
+class CUDASceneRepHashSDF:
+    def __init__(self, params, options=None, stream=None):
+        self.L = load()
+        self.stream = stream
+        self._params = _copy_struct(params)
+        self._options = _copy_struct(options) if options is not None else T.make_scene_options(offline=False)
+        h = C.c_void_p()
+        check(self.L.vh_scene_rep_create(C.byref(self._params), C.byref(self._options), stream, C.byref(h)), "vh_scene_rep_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_scene_rep_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API -------------------------------------------------------
+    def integrate(self, lastRigidTransform, depthCameraData, depthCameraParams, d_bitMask=None):
+        data = depthCameraData.data if isinstance(depthCameraData, DepthFrame) else depthCameraData
+        check(self.L.vh_scene_rep_integrate(self.handle, f16(lastRigidTransform), C.byref(data), C.byref(depthCameraParams), d_bitMask),
+              "CUDASceneRepHashSDF::integrate")
+
+    def setLastRigidTransformAndCompactify(self, lastRigidTransform, depthCameraParams):
+        check(self.L.vh_scene_rep_set_last_rigid_transform_and_compactify(self.handle, f16(lastRigidTransform), C.byref(depthCameraParams)),
+              "setLastRigidTransformAndCompactify")
+
+    def reset(self):
+        check(self.L.vh_scene_rep_reset(self.handle), "reset")
+
+    def getHashData(self):
+        hd = T.HashData()
+        check(self.L.vh_scene_rep_get_hash_data(self.handle, C.byref(hd)), "getHashData")
+        return hd
+
+    def getHashParams(self):
+        hp = T.HashParams()
+        check(self.L.vh_scene_rep_get_hash_params(self.handle, C.byref(hp)), "getHashParams")
+        return hp
+
+    def getLastRigidTransform(self):
+        return np.array(self.getHashParams().m_rigidTransform, dtype=np.float32).reshape(4, 4)
+
+    def getHeapFreeCount(self):
+        n = C.c_uint32()
+        check(self.L.vh_scene_rep_get_heap_free_count(self.handle, C.byref(n)), "getHeapFreeCount")
+        return n.value
+
+    def getNumOccupiedBlocks(self):
+        n = C.c_uint32()
+        check(self.L.vh_scene_rep_get_num_occupied_blocks(self.handle, C.byref(n)), "getNumOccupiedBlocks")
+        return n.value
+
+    def debugHash(self):
+        rep = (C.c_uint32 * 4)()
+        check(self.L.vh_scene_rep_debug_hash(self.handle, rep), "debugHash")
+        return dict(numOccupied=rep[0], numFree=rep[1], duplicates=rep[2], lockEntries=rep[3])
+
+    # ---- additions ---------------------------------------------------------------
+    def setOptions(self, options):
+        self._options = _copy_struct(options)
+        check(self.L.vh_scene_rep_set_options(self.handle, C.byref(self._options)), "setOptions")
+
+    def getState(self):
+        out = (C.c_uint32 * T.STATE_WORDS)()
+        check(self.L.vh_scene_rep_get_state(self.handle, out), "getState")
+        return np.array(out, dtype=np.uint32)
+
+    def getTimings(self):
+        out = (C.c_double * 4)()
+        check(self.L.vh_scene_rep_get_timings(self.handle, out), "getTimings")
+        return dict(alloc_ms=out[0], compactify_ms=out[1], integrate_ms=out[2], frames=int(out[3]))
+
+    def synchronize(self):
+        check(self.L.vh_stream_synchronize(self.stream), "synchronize")
+
+    # ---- downloads (test support) ---------------------------------------------------
+    def download(self, with_voxels=True):
+        """-> dict with the raw tables (hash, heap, counters, optionally voxels)"""
+        hp = self.getHashParams()
+        hd = self.getHashData()
+        ne = hp.m_hashNumBuckets * T.HASH_BUCKET_SIZE
+        s = self.stream
+        out = dict(
+            params=hp,
+            hash=download(hd.d_hash, T.HASH_ENTRY_DTYPE, ne, s),
+            heap=download(hd.d_heap, np.uint32, hp.m_numSDFBlocks, s),
+            heap_counter=int(download(hd.d_heapCounter, np.uint32, 1, s)[0]),
+            bucket_count=download(hd.d_bucketCount, np.uint32, hp.m_hashNumBuckets, s),
+            bucket_bits=download(hd.d_bucketBits, np.uint32, (hp.m_hashNumBuckets + 31) // 32, s),
+            compact_count=int(download(hd.d_hashCompactifiedCounter, np.int32, 1, s)[0]),
+        )
+        out["compactified"] = download(hd.d_hashCompactified, T.HASH_ENTRY_DTYPE, out["compact_count"], s)
+        out["decisions"] = download(hd.d_hashDecision, np.int32, out["compact_count"], s)
+        if with_voxels:
+            out["sdf_blocks"] = download(hd.d_SDFBlocks, T.VOXEL_DTYPE, hp.m_numSDFBlocks * T.SDF_BLOCK_VOXELS, s)
+        return out
+
+    def state(self, with_voxels=True, check_invariants=True):
+        """canonical snapshot (voxelhashing_amd.canonical) + invariant checks"""
+        d = self.download(with_voxels)
+        hp = d["params"]
+        if check_invariants:
+            canonical.check_invariants(d["hash"], d["heap"], d["heap_counter"], hp, d.get("sdf_blocks"))
+            canonical.check_bucket_summary(d["hash"], d["bucket_count"], d["bucket_bits"], hp)
+        snap = canonical.snapshot(d["hash"], d.get("sdf_blocks"), d["heap"], d["heap_counter"], hp, with_voxels)
+        snap["compactified"] = d["compactified"]
+        snap["decisions"] = d["decisions"]
+        return snap
+
+
+class CUDARayCastSDF:
+    def __init__(self, params, stream=None):
+        self.L = load()
+        self.stream = stream
+        self._params = _copy_struct(params)
+        h = C.c_void_p()
+        check(self.L.vh_raycast_create(C.byref(self._params), stream, C.byref(h)), "vh_raycast_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_raycast_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, hashData, hashParams, depthCameraParams, lastRigidTransform):
+        check(self.L.vh_raycast_render(self.handle, C.byref(hashData), C.byref(hashParams), C.byref(depthCameraParams),
+                                       f16(lastRigidTransform)), "CUDARayCastSDF::render")
+
+    def getRayCastData(self):
+        rd = T.RayCastData()
+        check(self.L.vh_raycast_get_data(self.handle, C.byref(rd)), "getRayCastData")
+        return rd
+
+    def getRayCastParams(self):
+        rp = T.RayCastParams()
+        check(self.L.vh_raycast_get_params(self.handle, C.byref(rp)), "getRayCastParams")
+        return rp
+
+    def setTiming(self, on):
+        check(self.L.vh_raycast_set_timing(self.handle, 1 if on else 0), "setTiming")
+
+    def getTimings(self):
+        out = (C.c_double * 3)()
+        check(self.L.vh_raycast_get_timings(self.handle, out), "getTimings")
+        return dict(raycast_ms=out[0], normals_ms=out[1], frames=int(out[2]))
+
+    def download(self):
+        rd = self.getRayCastData()
+        W, H = self._params.m_width, self._params.m_height
+        s = self.stream
+        return dict(
+            depth=download(rd.d_depth, np.float32, H * W, s).reshape(H, W),
+            depth4=download(rd.d_depth4, np.float32, H * W * 4, s).reshape(H, W, 4),
+            normals=download(rd.d_normals, np.float32, H * W * 4, s).reshape(H, W, 4),
+            colors=download(rd.d_colors, np.float32, H * W * 4, s).reshape(H, W, 4),
+        )
+
+
+class CUDASceneRepChunkGrid:
+    def __init__(self, sceneRepHashSDF, voxelExtends, gridDimensions, minGridPos, initialChunkListSize,
+                 streamingEnabled, streamOutParts):
+        self.L = load()
+        self.scene = sceneRepHashSDF
+        h = C.c_void_p()
+        ext = np.asarray(voxelExtends, dtype=np.float32)
+        dims = (C.c_int32 * 3)(*[int(v) for v in gridDimensions])
+        mn = (C.c_int32 * 3)(*[int(v) for v in minGridPos])
+        check(self.L.vh_chunk_grid_create(sceneRepHashSDF.handle, f16(ext), dims, mn, initialChunkListSize,
+                                          1 if streamingEnabled else 0, streamOutParts, C.byref(h)), "vh_chunk_grid_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_chunk_grid_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def streamOutToCPUPass0GPU(self, posCamera, radius, useParts=True, multiThreaded=True):
+        check(self.L.vh_chunk_grid_stream_out_to_cpu_pass0_gpu(self.handle, f16(posCamera), radius, int(useParts), int(multiThreaded)),
+              "streamOutToCPUPass0GPU")
+
+    def streamOutToCPUPass1CPU(self, multiThreaded=True):
+        check(self.L.vh_chunk_grid_stream_out_to_cpu_pass1_cpu(self.handle, int(multiThreaded)), "streamOutToCPUPass1CPU")
+
+    def streamInToGPUPass0CPU(self, posCamera, radius, useParts=True, multiThreaded=True):
+        check(self.L.vh_chunk_grid_stream_in_to_gpu_pass0_cpu(self.handle, f16(posCamera), radius, int(useParts), int(multiThreaded)),
+              "streamInToGPUPass0CPU")
+
+    def streamInToGPUPass1GPU(self, multiThreaded=True):
+        check(self.L.vh_chunk_grid_stream_in_to_gpu_pass1_gpu(self.handle, int(multiThreaded)), "streamInToGPUPass1GPU")
+
+    def streamOutToCPU(self, posCamera, radius, useParts=True):
+        n = C.c_uint32()
+        check(self.L.vh_chunk_grid_stream_out_to_cpu(self.handle, f16(posCamera), radius, int(useParts), C.byref(n)), "streamOutToCPU")
+        return n.value
+
+    def streamInToGPU(self, posCamera, radius, useParts=True):
+        n = C.c_uint32()
+        check(self.L.vh_chunk_grid_stream_in_to_gpu(self.handle, f16(posCamera), radius, int(useParts), C.byref(n)), "streamInToGPU")
+        return n.value
+
+    def streamOutToCPUAll(self):
+        check(self.L.vh_chunk_grid_stream_out_to_cpu_all(self.handle), "streamOutToCPUAll")
+
+    def streamInToGPUAll(self, posCamera, radius, useParts=True):
+        n = C.c_uint32()
+        check(self.L.vh_chunk_grid_stream_in_to_gpu_all(self.handle, f16(posCamera), radius, int(useParts), C.byref(n)), "streamInToGPUAll")
+        return n.value
+
+    def getBitMaskGPU(self):
+        p = C.c_void_p()
+        check(self.L.vh_chunk_grid_get_bit_mask_gpu(self.handle, C.byref(p)), "getBitMaskGPU")
+        return p
+
+    def reset(self):
+        check(self.L.vh_chunk_grid_reset(self.handle), "reset")
+
+    def debugCheckForDuplicates(self):
+        check(self.L.vh_chunk_grid_debug_check_for_duplicates(self.handle), "debugCheckForDuplicates")
+
+    def getStatistics(self):
+        out = (C.c_uint32 * 3)()
+        check(self.L.vh_chunk_grid_get_statistics(self.handle, out), "getStatistics")
+        return dict(chunks=out[0], blocks=out[1], bits=out[2])
+
+    def downloadHostBlocks(self):
+        n = C.c_uint32()
+        check(self.L.vh_chunk_grid_download_host_blocks(self.handle, None, None, 0, C.byref(n)), "downloadHostBlocks")
+        descs = np.zeros(n.value, dtype=T.DESC_DTYPE)
+        blocks = np.zeros((n.value, T.SDF_BLOCK_VOXELS), dtype=T.VOXEL_DTYPE)
+        if n.value:
+            check(self.L.vh_chunk_grid_download_host_blocks(self.handle, descs.ctypes.data, blocks.ctypes.data, n.value, C.byref(n)),
+                  "downloadHostBlocks")
+        return descs, blocks
+
+    def saveToFile(self, filename, camPos, radius):
+        check(self.L.vh_chunk_grid_save_to_file(self.handle, filename.encode(), f16(camPos), radius), "saveToFile")
+
+    def loadFromFile(self, filename, camPos, radius):
+        check(self.L.vh_chunk_grid_load_from_file(self.handle, filename.encode(), f16(camPos), radius), "loadFromFile")

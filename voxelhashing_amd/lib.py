@@ -1,0 +1,176 @@
+"""Loader and ctypes prototypes of libvoxelhashing_amd.so (include/vh_api.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this
+module raises.  (Building needs only hipcc, not a GPU: voxelhashing_amd.build.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import vhtypes as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvoxelhashing_amd.so")
+_LIB = None
+
+P = C.POINTER
+_F16 = P(C.c_float)
+_VP = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/vh_api.h declares
+PROTOTYPES = {
+    "vh_version": (C.c_char_p, []),
+    "vh_error_string": (C.c_char_p, [C.c_int]),
+    "vh_last_error_message": (C.c_char_p, []),
+    "vh_malloc": (C.c_int, [P(_VP), C.c_size_t]),
+    "vh_free": (C.c_int, [_VP]),
+    "vh_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
+    "vh_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
+    "vh_memset": (C.c_int, [_VP, C.c_int, C.c_size_t, _VP]),
+    "vh_stream_synchronize": (C.c_int, [_VP]),
+    "vh_device_synchronize": (C.c_int, []),
+    "vh_hash_data_alloc": (C.c_int, [P(T.HashData), P(T.HashParams)]),
+    "vh_hash_data_free": (C.c_int, [P(T.HashData)]),
+    "vh_reset": (C.c_int, [P(T.HashData), P(T.HashParams), _VP]),
+    "vh_reset_bucket_mutex": (C.c_int, [P(T.HashData), P(T.HashParams), _VP]),
+    "vh_alloc": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), _VP, C.c_int32, _VP]),
+    "vh_compactify": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(C.c_uint32), _VP]),
+    "vh_integrate": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), _VP]),
+    "vh_starve": (C.c_int, [P(T.HashData), P(T.HashParams), _VP]),
+    "vh_gc_identify": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _VP]),
+    "vh_gc_free": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_int32, _VP]),
+    "vh_bind_input_depth_color_textures": (C.c_int, [P(T.DepthCameraData)]),
+    "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP]),
+    "vh_render": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP]),
+    "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
+    "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
+    "vh_stream_in_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP]),
+    "vh_stream_in_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, _VP, _VP]),
+    "vh_synth_frame": (C.c_int, [_VP, C.c_int, C.c_int, _F16, P(T.DepthCameraParams), _VP, _VP, _VP]),
+    "vh_debug_hash_ops": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
+    "vh_scene_rep_create": (C.c_int, [P(T.HashParams), P(T.SceneOptions), _VP, P(_VP)]),
+    "vh_scene_rep_destroy": (None, [_VP]),
+    "vh_scene_rep_integrate": (C.c_int, [_VP, _F16, P(T.DepthCameraData), P(T.DepthCameraParams), _VP]),
+    "vh_scene_rep_set_last_rigid_transform_and_compactify": (C.c_int, [_VP, _F16, P(T.DepthCameraParams)]),
+    "vh_scene_rep_reset": (C.c_int, [_VP]),
+    "vh_scene_rep_get_hash_data": (C.c_int, [_VP, P(T.HashData)]),
+    "vh_scene_rep_get_hash_params": (C.c_int, [_VP, P(T.HashParams)]),
+    "vh_scene_rep_get_heap_free_count": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_scene_rep_get_num_occupied_blocks": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_scene_rep_debug_hash": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_scene_rep_get_state": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_scene_rep_get_timings": (C.c_int, [_VP, P(C.c_double)]),
+    "vh_scene_rep_set_options": (C.c_int, [_VP, P(T.SceneOptions)]),
+    "vh_raycast_create": (C.c_int, [P(T.RayCastParams), _VP, P(_VP)]),
+    "vh_raycast_destroy": (None, [_VP]),
+    "vh_raycast_render": (C.c_int, [_VP, P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _F16]),
+    "vh_raycast_get_data": (C.c_int, [_VP, P(T.RayCastData)]),
+    "vh_raycast_get_params": (C.c_int, [_VP, P(T.RayCastParams)]),
+    "vh_raycast_get_timings": (C.c_int, [_VP, P(C.c_double)]),
+    "vh_raycast_set_timing": (C.c_int, [_VP, C.c_int]),
+    "vh_chunk_grid_create": (C.c_int, [_VP, _F16, P(C.c_int32), P(C.c_int32), C.c_uint32, C.c_int, C.c_uint32, P(_VP)]),
+    "vh_chunk_grid_destroy": (None, [_VP]),
+    "vh_chunk_grid_stream_out_to_cpu_pass0_gpu": (C.c_int, [_VP, _F16, C.c_float, C.c_int, C.c_int]),
+    "vh_chunk_grid_stream_out_to_cpu_pass1_cpu": (C.c_int, [_VP, C.c_int]),
+    "vh_chunk_grid_stream_in_to_gpu_pass0_cpu": (C.c_int, [_VP, _F16, C.c_float, C.c_int, C.c_int]),
+    "vh_chunk_grid_stream_in_to_gpu_pass1_gpu": (C.c_int, [_VP, C.c_int]),
+    "vh_chunk_grid_stream_out_to_cpu": (C.c_int, [_VP, _F16, C.c_float, C.c_int, P(C.c_uint32)]),
+    "vh_chunk_grid_stream_in_to_gpu": (C.c_int, [_VP, _F16, C.c_float, C.c_int, P(C.c_uint32)]),
+    "vh_chunk_grid_stream_out_to_cpu_all": (C.c_int, [_VP]),
+    "vh_chunk_grid_stream_in_to_gpu_all": (C.c_int, [_VP, _F16, C.c_float, C.c_int, P(C.c_uint32)]),
+    "vh_chunk_grid_get_bit_mask_gpu": (C.c_int, [_VP, P(_VP)]),
+    "vh_chunk_grid_reset": (C.c_int, [_VP]),
+    "vh_chunk_grid_debug_check_for_duplicates": (C.c_int, [_VP]),
+    "vh_chunk_grid_get_statistics": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_chunk_grid_download_host_blocks": (C.c_int, [_VP, _VP, _VP, C.c_uint32, P(C.c_uint32)]),
+    "vh_chunk_grid_save_to_file": (C.c_int, [_VP, C.c_char_p, _F16, C.c_float]),
+    "vh_chunk_grid_load_from_file": (C.c_int, [_VP, C.c_char_p, _F16, C.c_float]),
+}
+
+
+class VhError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(what)
+
+
+def load():
+    """dlopen the in-tree HIP library; raises if it has not been built"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m voxelhashing_amd.build` "
+                           "(hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(code, what=""):
+    if code != 0:
+        L = load()
+        msg = L.vh_error_string(code).decode()
+        extra = L.vh_last_error_message().decode()
+        raise VhError(code, f"{what}: {msg} (code {code}){' -- ' + extra if extra else ''}")
+
+
+def f16(m):
+    a = np.ascontiguousarray(m, dtype=np.float32).reshape(-1)
+    return a.ctypes.data_as(_F16)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer owned through vh_malloc/vh_free."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(load().vh_malloc(C.byref(p), max(self.nbytes, 1)), "vh_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a, stream=None):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        b.upload(a, stream)
+        return b
+
+    def upload(self, a, stream=None):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        if a.nbytes:
+            check(load().vh_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes, stream), "vh_memcpy_h2d")
+
+    def download(self, dtype, count=None, stream=None):
+        dt = np.dtype(dtype)
+        n = self.nbytes // dt.itemsize if count is None else count
+        out = np.empty(n, dtype=dt)
+        if out.nbytes:
+            check(load().vh_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, stream), "vh_memcpy_d2h")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            load().vh_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def download(ptr, dtype, count, stream=None):
+    """copy `count` items of `dtype` from a raw device pointer"""
+    out = np.empty(count, dtype=np.dtype(dtype))
+    if out.nbytes:
+        check(load().vh_memcpy_d2h(out.ctypes.data, ptr, out.nbytes, stream), "vh_memcpy_d2h")
+    return out
