@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py -- depth frames/sec of the integrate+raycast frame loop on MI355X.
+
+Metric (BASELINE.json): depth frames/sec integrate+raycast @640x480, 4 cm voxel.
+Workload (config.workload = cfg2): synthetic orbiting-sphere sequence S1,
+640x480, 4 cm voxels, 500 k hash buckets (5 M entries), 1 M SDF blocks,
+alloc + compactify + integrate + garbage-collect + raycast + normals per frame,
+in the reference's order (render with the previous pose, then integrate;
+DepthSensingCUDA/Source/DepthSensing.cpp:763,903).  A "step" is one frame.
+Inputs (depth + colour of every frame) are generated on the device before the
+timed region and stay resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one process per GPU, one independent
+scene per GPU (orbit phase-shifted by 2*pi*rank/8); weak scaling; RCCL is used
+only for the start/stop barriers and a MAX-reduce of the elapsed time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed
+inside the timed region) and `cpu_baseline` (the CPU oracle timed on a bounded
+sample of the same workload, rank 0 at N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=900)
+    p.add_argument("--warmup", type=int, default=100)
+    p.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    p.add_argument("--offline", action="store_true", help="alloc until fixed point (blocking read-backs), as in parity runs")
+    p.add_argument("--no-gc", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-frames", type=int, default=16, help="frames of the workload timed on the CPU oracle")
+    p.add_argument("--stages", action="store_true", help="also print per-stage device times to stderr")
+    p.add_argument("--scene", default=None, help="override the scene (S1, S2)")
+    return p.parse_args()
+
+
+def dist_setup(n_gpus):
+    """-> (rank, world, local_rank, dist or None)"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n_gpus <= 1 and world <= 1:
+        return 0, 1, 0, None
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank, dist
+
+
+def barrier(dist_mod):
+    if dist_mod is not None:
+        dist_mod.barrier()
+
+
+def max_over_ranks(dist_mod, value, device):
+    if dist_mod is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist_mod, value, device):
+    if dist_mod is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist_mod.all_reduce(t, op=dist_mod.ReduceOp.SUM)
+    return float(t.item())
+
+
+class GpuWorkload:
+    """one scene on one GPU: pre-generated frames + the reference frame loop"""
+
+    def __init__(self, cfg_name, n_frames, rank, args):
+        import torch
+        from voxelhashing_amd import engine as E, synth, vhtypes as T
+        self.torch, self.E, self.T, self.synth = torch, E, T, synth
+        cfg = dict(synth.CONFIGS[cfg_name])
+        if args.scene:
+            cfg["scene"] = args.scene
+        self.cfg = cfg
+        self.hp, self.cp, self.rp = synth.config_params(cfg)
+        self.opt = T.make_scene_options(offline=args.offline, gc=not args.no_gc, starve=15, timings=True)
+        spheres, inside, radius = synth.scene(cfg["scene"])
+        self.n_frames = n_frames
+        phase = 2.0 * math.pi * rank / 8.0
+        self.poses = [synth.orbit_pose(k, 1000, radius, phase) for k in range(n_frames)]
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        H, W = self.cp.m_imageHeight, self.cp.m_imageWidth
+        # inputs resident in HBM: torch owns the frame store, the engine reads raw pointers
+        self.depth = torch.empty((n_frames, H, W), dtype=torch.float32, device=self.dev)
+        self.color = torch.empty((n_frames, H, W, 4), dtype=torch.float32, device=self.dev)
+        self.frames = []
+        for k in range(n_frames):
+            fr = E.DepthFrame(self.cp, depth_ptr=self.depth[k].data_ptr(), color_ptr=self.color[k].data_ptr())
+            E.synth_frame(spheres, inside, self.poses[k], self.cp, out=fr)
+            self.frames.append(fr)
+        self.scene = E.CUDASceneRepHashSDF(self.hp, self.opt)
+        self.ray = E.CUDARayCastSDF(self.rp)
+        self.ray.setTiming(True)
+        self.hd = self.scene.getHashData()
+        torch.cuda.synchronize()
+
+    def run(self, k0, k1):
+        """frames k0..k1-1 of the sequence in the reference's order"""
+        scene, ray, cp, hd = self.scene, self.ray, self.cp, self.hd
+        for k in range(k0, k1):
+            if k > 0:
+                ray.render(hd, scene.getHashParams(), cp, self.poses[k - 1])
+            scene.integrate(self.poses[k], self.frames[k], cp, None)
+
+    def timings(self):
+        s = self.scene.getTimings()
+        r = self.ray.getTimings()
+        s.update(r)
+        return s
+
+
+def stage_bytes(cfg_hp, cp, n_occ, stage):
+    """ALGORITHMIC bytes per launch (E = 20 B entry payload, V = 8 B voxel)"""
+    W, H = cp.m_imageWidth, cp.m_imageHeight
+    E, V = 20, 8
+    if stage == "raycast":
+        return 52.0 * W * H
+    if stage == "integrate":
+        return n_occ * (E + 512 * V * 2) + 4.0 * W * H + 16.0 * W * H
+    if stage == "alloc":
+        return 4.0 * W * H
+    if stage == "compactify":
+        return 4.0 * cfg_hp.m_hashNumBuckets * 10 + 2.0 * E * n_occ
+    if stage == "normals":
+        return (16.0 * 5 + 16.0) * W * H
+    raise KeyError(stage)
+
+
+def cpu_baseline(cfg_name, n_frames, args):
+    """the CPU oracle (single thread) on the first n_frames of the same workload"""
+    from oracle import oracle as O
+    from voxelhashing_amd import synth, vhtypes as T
+    cfg = dict(synth.CONFIGS[cfg_name])
+    if args.scene:
+        cfg["scene"] = args.scene
+    hp, cp, rp = synth.config_params(cfg)
+    opt = T.make_scene_options(offline=args.offline, gc=not args.no_gc, starve=15)
+    spheres, inside, radius = synth.scene(cfg["scene"])
+    sc = O.OracleScene(hp, cp, rp, opt)
+    poses = [synth.orbit_pose(k, 1000, radius, 0.0) for k in range(n_frames)]
+    inputs = [O.synth_frame(spheres, inside, p, cp) for p in poses]
+    t0 = time.perf_counter()
+    for k in range(n_frames):
+        if k > 0:
+            sc.render(poses[k - 1])
+        sc.integrate(poses[k], inputs[k][0], inputs[k][1])
+    dt = time.perf_counter() - t0
+    sc.close()
+    return dict(value=n_frames / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"first {n_frames} frames of {cfg_name} ({cfg['scene']}), oracle/libvh_oracle.so, 1 thread, {dt:.1f} s")
+
+
+def main():
+    args = parse_args()
+    rank, world, local_rank, dist_mod = dist_setup(args.gpus)
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n_frames = args.warmup + args.steps
+    wl = GpuWorkload(args.config, n_frames, rank, args)
+
+    # warmup (untimed)
+    wl.run(0, args.warmup)
+    torch.cuda.synchronize()
+    wl.timings()  # fold and discard warm-up stage times
+    pre = wl.timings()
+
+    barrier(dist_mod)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl.run(args.warmup, n_frames)
+    torch.cuda.synchronize()
+    barrier(dist_mod)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(dist_mod, elapsed, dev)
+
+    post = wl.timings()
+    n_occ = wl.scene.getNumOccupiedBlocks()
+    total_frames = sum_over_ranks(dist_mod, float(args.steps), dev)
+    value = total_frames / elapsed
+
+    # per-stage device time inside the timed region (HIP events on the launch stream)
+    stages = {}
+    for key, cnt_key in (("alloc_ms", "frames"), ("compactify_ms", "frames"), ("integrate_ms", "frames"),
+                         ("raycast_ms", "frames"), ("normals_ms", "frames")):
+        stages[key[:-3]] = (post[key] - pre[key])
+    launches = max(args.steps, 1)
+    per_launch_us = {k: 1e3 * v / launches for k, v in stages.items()}
+    dominant = max(per_launch_us, key=per_launch_us.get)
+    alg_bytes = stage_bytes(wl.hp, wl.cp, n_occ, dominant)
+    achieved = alg_bytes / (per_launch_us[dominant] * 1e-6) / 1e9 if per_launch_us[dominant] > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                tj = json.load(f)
+            traffic = tj.get(args.config, {}).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
+                    algorithmic_bytes=alg_bytes, avg_launch_us=round(per_launch_us[dominant], 3),
+                    stage_us={k: round(v, 3) for k, v in per_launch_us.items()}, blocks_in_frustum=n_occ)
+
+    result = None
+    if rank == 0:
+        cfg = wl.cfg
+        result = {
+            "metric": "depth frames/sec integrate+raycast @640x480, 4 cm voxel; HBM GB/s vs peak",
+            "value": round(value, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {cfg['scene']} orbit, {cfg['width']}x{cfg['height']}, {cfg['params']} voxels, "
+                            f"{cfg['num_buckets']} buckets, {cfg['num_sdf_blocks']} SDF blocks, "
+                            f"alloc+compactify+integrate+{'gc+' if not args.no_gc else ''}raycast+normals per frame",
+                "alloc_mode": "offline (fixed point)" if args.offline else "online (one pass per frame)",
+                "streams": "one independent scene per GPU",
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames, args)
+            except Exception as e:  # the baseline must never sink the GPU result
+                result["cpu_baseline"] = dict(value=None, unit="frames/s", cores=1, kind="port", sample=f"failed: {e}")
+        else:
+            result["cpu_baseline"] = None
+        if args.stages:
+            print(json.dumps(per_launch_us), file=sys.stderr)
+        print(json.dumps(result), flush=True)
+    if dist_mod is not None:
+        dist_mod.barrier()
+        dist_mod.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()
