@@ -91,3 +91,17 @@ def test_orbit_gc_sequence(E, oracle_lib, reference_sequence):
     g, r, o = run_pair(E, oracle_lib, hp, cp, rp, opt, poses, synth.S1_SPHERES)
     st = g.getState()
     assert st[T.STATE_HEAP_UNDERFLOW] == 0 and st[T.STATE_INSERT_FAILED] == 0
+
+
+def test_raycast_with_gradients(E, oracle_lib):
+    """m_useGradients = true: normals from gradientForPoint (6 trilinear samples
+    whose partial sums on failure are observable) instead of computeNormals"""
+    hp, cp, _ = small_config(128, 96)
+    rp = T.make_raycast_params(hp, cp, use_gradients=True)
+    opt = T.make_scene_options(offline=True, gc=False)
+    poses = [synth.orbit_pose(k, n_frames=100) for k in range(3)]
+    g, r, o = run_pair(E, oracle_lib, hp, cp, rp, opt, poses, synth.S1_SPHERES)
+    r.render(g.getHashData(), g.getHashParams(), cp, poses[-1])
+    got, want = r.download(), o.render(poses[-1])
+    assert_maps_equal(got, want, "gradients")
+    assert (got["normals"][..., 3] == 1.0).sum() > 500

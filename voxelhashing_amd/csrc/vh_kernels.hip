@@ -377,103 +377,181 @@ __global__ __launch_bounds__(256) void k_gc_free(VhHashData hd, VhHashParams hp,
 // traverseCoarseGridSimpleSampleAll DSC/RayCastSDFUtil.h:198-262)
 //
 // One wave per 8x8 pixel tile (rays of a tile stay in the same few blocks).
-// Per ray: a one-entry block cache (block id -> ptr) so the 8 taps of a
-// sample and consecutive samples re-probe the table only when they change
-// block, and the bucket-occupancy bit turns a probe of empty space into a
-// single cached dword test.  Every arithmetic step, its order and every
-// early-out is the reference's.
+// The reference's march is a chain of dependent gathers (8 hash probes x up to
+// 11 entry loads + 8 voxel loads per sample, one after the other).  On MI355X
+// that chain, not bandwidth or ALU, sets the kernel time (rocprof: ~137
+// serialized loads per wave), so the work is re-ordered to put independent
+// loads in flight together -- without changing a single arithmetic operation,
+// its order, or an early-out:
+//   * empty space: the first tap of the next 4 samples is resolved at once
+//     (block id -> occupancy bit of its bucket: one cached dword each); a
+//     sample whose first tap has no block is invalid, exactly as in the
+//     reference, and costs no table access;
+//   * a sample with a first tap: block pointers of the (1..8) blocks the 8
+//     taps touch come from a 2-entry per-ray cache or a bucket probe; then all
+//     8 voxels are loaded together and weighted/accumulated in the reference's
+//     tap order;
+//   * march and bisection share ONE sample-evaluation site (a small state
+//     machine), which keeps the kernel at a few dozen VGPRs.
 // ---------------------------------------------------------------------------
 
 struct BlockCache {
-    int bx, by, bz, ptr;
-    bool valid;
+    int bx0, by0, bz0, p0;
+    int bx1, by1, bz1, p1;
+    bool v0, v1;
 };
 
-VHD bool fetch_voxel(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, int vx, int vy, int vz, Vox& v)
+VHD void cache_init(BlockCache& bc)
 {
-    const int bx = vvp_to_block1(vx), by = vvp_to_block1(vy), bz = vvp_to_block1(vz);
-    if (!(bc.valid && bc.bx == bx && bc.by == by && bc.bz == bz)) {
-        bc.ptr = lookup_ptr(hd, hp, mki3(bx, by, bz));
-        bc.bx = bx; bc.by = by; bc.bz = bz; bc.valid = true;
-    }
-    if (bc.ptr == VH_FREE_ENTRY) return false; // getVoxel returns the zero voxel: weight 0
-    const uint2 w = *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)bc.ptr + (uint32_t)vvp_to_local_index(mki3(vx, vy, vz))]);
-    v = unpack_vox(w);
-    return v.weight() != 0u;
+    bc.v0 = bc.v1 = false;
+    bc.bx0 = bc.by0 = bc.bz0 = bc.bx1 = bc.by1 = bc.bz1 = 0;
+    bc.p0 = bc.p1 = VH_FREE_ENTRY;
 }
 
-// trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116
+VHD int cached_lookup(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, int bx, int by, int bz)
+{
+    if (bc.v0 && bc.bx0 == bx && bc.by0 == by && bc.bz0 == bz) return bc.p0;
+    if (bc.v1 && bc.bx1 == bx && bc.by1 == by && bc.bz1 == bz) return bc.p1;
+    const int p = lookup_ptr(hd, hp, mki3(bx, by, bz));
+    bc.bx1 = bc.bx0; bc.by1 = bc.by0; bc.bz1 = bc.bz0; bc.p1 = bc.p0; bc.v1 = bc.v0;
+    bc.bx0 = bx; bc.by0 = by; bc.bz0 = bz; bc.p0 = p; bc.v0 = true;
+    return p;
+}
+
+VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
+{
+    return *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]);
+}
+
+// trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116.
+// Returns false exactly when the reference does (some tap, in tap order, has
+// weight 0 -- a missing block yields the zero voxel); `dist` is then undefined
+// (the reference leaves a partial sum that only gradientForPoint can observe:
+// see trilinear_partial below).
 VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 pos, float& dist, uint32_t& colorOut)
 {
     const float vs = hp.m_virtualVoxelSize;
     const float oSet = vs;
     const float h = oSet / 2.0f;
     const F3 pd = mk3(pos.x - h, pos.y - h, pos.z - h);
+
+    const int x0 = world_to_vvp1(pd.x, vs), y0 = world_to_vvp1(pd.y, vs), z0 = world_to_vvp1(pd.z, vs);
+    const int x1 = world_to_vvp1(pd.x + oSet, vs), y1 = world_to_vvp1(pd.y + oSet, vs), z1 = world_to_vvp1(pd.z + oSet, vs);
+    const int bxa = vvp_to_block1(x0), bya = vvp_to_block1(y0), bza = vvp_to_block1(z0);
+    const int bxb = vvp_to_block1(x1), byb = vvp_to_block1(y1), bzb = vvp_to_block1(z1);
+    // bit a of `straddle`: the tap pair along axis a lies in two different blocks
+    const uint32_t straddle = (bxb != bxa ? 1u : 0u) | (byb != bya ? 2u : 0u) | (bzb != bza ? 4u : 0u);
+
+    // block pointer per tap combo (bit0 = x1, bit1 = y1, bit2 = z1); one probe per DISTINCT block
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
+    uint32_t need = 0xffu;
+#pragma unroll 1
+    while (need) {
+        const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
+        const int p = cached_lookup(hd, hp, bc, (k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
+        if (p == VH_FREE_ENTRY) return false; // that tap reads the zero voxel (weight 0)
+        const uint32_t km = k & straddle;
+        if (((0u) & straddle) == km) p0 = p;
+        if (((1u) & straddle) == km) p1 = p;
+        if (((2u) & straddle) == km) p2 = p;
+        if (((3u) & straddle) == km) p3 = p;
+        if (((4u) & straddle) == km) p4 = p;
+        if (((5u) & straddle) == km) p5 = p;
+        if (((6u) & straddle) == km) p6 = p;
+        if (((7u) & straddle) == km) p7 = p;
+        uint32_t same = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) same |= (((j & straddle) == km) ? 1u : 0u) << j;
+        need &= ~same;
+    }
+
+    const int lx0 = local1(x0), ly0 = local1(y0), lz0 = local1(z0);
+    const int lx1 = local1(x1), ly1 = local1(y1), lz1 = local1(z1);
+    // the eight voxels, in flight together (reference tap order 000,100,010,001,110,011,101,111)
+    const Vox v000 = unpack_vox(load_voxel(hd, p0, lx0, ly0, lz0));
+    const Vox v100 = unpack_vox(load_voxel(hd, p1, lx1, ly0, lz0));
+    const Vox v010 = unpack_vox(load_voxel(hd, p2, lx0, ly1, lz0));
+    const Vox v001 = unpack_vox(load_voxel(hd, p4, lx0, ly0, lz1));
+    const Vox v110 = unpack_vox(load_voxel(hd, p3, lx1, ly1, lz0));
+    const Vox v011 = unpack_vox(load_voxel(hd, p6, lx0, ly1, lz1));
+    const Vox v101 = unpack_vox(load_voxel(hd, p5, lx1, ly0, lz1));
+    const Vox v111 = unpack_vox(load_voxel(hd, p7, lx1, ly1, lz1));
+    if (v000.weight() == 0u || v100.weight() == 0u || v010.weight() == 0u || v001.weight() == 0u ||
+        v110.weight() == 0u || v011.weight() == 0u || v101.weight() == 0u || v111.weight() == 0u)
+        return false;
+
     const float fx = pos.x / vs, fy = pos.y / vs, fz = pos.z / vs;
     const float wx = fx - floorf(fx), wy = fy - floorf(fy), wz = fz - floorf(fz);
-
-    const int x0 = world_to_vvp1(pd.x, vs), x1 = world_to_vvp1(pd.x + oSet, vs);
-    const int y0 = world_to_vvp1(pd.y, vs), y1 = world_to_vvp1(pd.y + oSet, vs);
-    const int z0 = world_to_vvp1(pd.z, vs), z1 = world_to_vvp1(pd.z + oSet, vs);
-
     float d = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    Vox v;
-#define VH_TAP(VX, VY, VZ, WX, WY, WZ)                                  \
-    if (!fetch_voxel(hd, hp, bc, VX, VY, VZ, v)) { dist = d; return false; } \
+#define VH_ACC(V, WX, WY, WZ)                                           \
     {                                                                   \
         const float s = (WX) * (WY) * (WZ);                             \
-        d += s * v.sdf;                                                 \
-        cr += s * (float)v.r(); cg += s * (float)v.g(); cb += s * (float)v.b(); \
+        d += s * (V).sdf;                                               \
+        cr += s * (float)(V).r(); cg += s * (float)(V).g(); cb += s * (float)(V).b(); \
     }
-    VH_TAP(x0, y0, z0, 1.0f - wx, 1.0f - wy, 1.0f - wz)
-    VH_TAP(x1, y0, z0, wx, 1.0f - wy, 1.0f - wz)
-    VH_TAP(x0, y1, z0, 1.0f - wx, wy, 1.0f - wz)
-    VH_TAP(x0, y0, z1, 1.0f - wx, 1.0f - wy, wz)
-    VH_TAP(x1, y1, z0, wx, wy, 1.0f - wz)
-    VH_TAP(x0, y1, z1, 1.0f - wx, wy, wz)
-    VH_TAP(x1, y0, z1, wx, 1.0f - wy, wz)
-    VH_TAP(x1, y1, z1, wx, wy, wz)
-#undef VH_TAP
+    VH_ACC(v000, 1.0f - wx, 1.0f - wy, 1.0f - wz)
+    VH_ACC(v100, wx, 1.0f - wy, 1.0f - wz)
+    VH_ACC(v010, 1.0f - wx, wy, 1.0f - wz)
+    VH_ACC(v001, 1.0f - wx, 1.0f - wy, wz)
+    VH_ACC(v110, wx, wy, 1.0f - wz)
+    VH_ACC(v011, 1.0f - wx, wy, wz)
+    VH_ACC(v101, wx, 1.0f - wy, wz)
+    VH_ACC(v111, wx, wy, wz)
+#undef VH_ACC
     dist = d;
     colorOut = (uint32_t)f2uc(cr) | ((uint32_t)f2uc(cg) << 8) | ((uint32_t)f2uc(cb) << 16);
     return true;
 }
 
-// findIntersectionBisection :149-170 over findIntersectionLinear :140-143
-VHD bool intersect_bisection(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 camPos, F3 dir,
-                             float d0, float r0, float d1, float r1, float& alpha, uint32_t& color)
+// The same function with the reference's tap-by-tap early-out, leaving the
+// partial sum in `dist` on failure: gradientForPoint (:174-195) ignores the
+// return value and uses that partial sum.
+__device__ __noinline__ float trilinear_partial(const VhHashData hd, const VhHashParams hp, BlockCache bc, float px, float py, float pz)
 {
-    float a = r0, aDist = d0, b = r1, bDist = d1, c = 0.0f;
+    const float vs = hp.m_virtualVoxelSize;
+    const float oSet = vs;
+    const float h = oSet / 2.0f;
+    const F3 pd = mk3(px - h, py - h, pz - h);
+    const float fx = px / vs, fy = py / vs, fz = pz / vs;
+    const float wx = fx - floorf(fx), wy = fy - floorf(fy), wz = fz - floorf(fz);
+    float d = 0.0f;
 #pragma unroll 1
-    for (int i = 0; i < 3; i++) {
-        c = a + (aDist / (aDist - bDist)) * (b - a);
-        float cDist;
-        if (!trilinear(hd, hp, bc, mk3(camPos.x + c * dir.x, camPos.y + c * dir.y, camPos.z + c * dir.z), cDist, color)) return false;
-        if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
-        else { b = c; bDist = cDist; }
+    for (uint32_t k = 0; k < 8u; k++) {
+        // reference tap order 000,100,010,001,110,011,101,111 as (x,y,z) bit triples
+        const uint32_t combo = (0x75634210u >> (4u * k)) & 7u; // k-th nibble: 0,1,2,4,3,6,5,7
+        const bool bx = combo & 1u, by = combo & 2u, bz = combo & 4u;
+        const int vx = world_to_vvp1(bx ? pd.x + oSet : pd.x, vs);
+        const int vy = world_to_vvp1(by ? pd.y + oSet : pd.y, vs);
+        const int vz = world_to_vvp1(bz ? pd.z + oSet : pd.z, vs);
+        const int p = cached_lookup(hd, hp, bc, vvp_to_block1(vx), vvp_to_block1(vy), vvp_to_block1(vz));
+        if (p == VH_FREE_ENTRY) return d;
+        const Vox v = unpack_vox(load_voxel(hd, p, local1(vx), local1(vy), local1(vz)));
+        if (v.weight() == 0u) return d;
+        const float s = (bx ? wx : 1.0f - wx) * (by ? wy : 1.0f - wy) * (bz ? wz : 1.0f - wz);
+        d += s * v.sdf;
     }
-    alpha = c;
-    return true;
+    return d;
 }
 
 // gradientForPoint :174-195
-VHD F3 gradient_for_point(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 pos)
+VHD F3 gradient_for_point(const VhHashData& hd, const VhHashParams& hp, const BlockCache& bc, F3 pos)
 {
     const float vs = hp.m_virtualVoxelSize;
-    float dp00 = 0.0f, d0p0 = 0.0f, d00p = 0.0f, d100 = 0.0f, d010 = 0.0f, d001 = 0.0f;
-    uint32_t c;
-    trilinear(hd, hp, bc, mk3(pos.x - 0.5f * vs, pos.y - 0.0f, pos.z - 0.0f), dp00, c);
-    trilinear(hd, hp, bc, mk3(pos.x - 0.0f, pos.y - 0.5f * vs, pos.z - 0.0f), d0p0, c);
-    trilinear(hd, hp, bc, mk3(pos.x - 0.0f, pos.y - 0.0f, pos.z - 0.5f * vs), d00p, c);
-    trilinear(hd, hp, bc, mk3(pos.x + 0.5f * vs, pos.y + 0.0f, pos.z + 0.0f), d100, c);
-    trilinear(hd, hp, bc, mk3(pos.x + 0.0f, pos.y + 0.5f * vs, pos.z + 0.0f), d010, c);
-    trilinear(hd, hp, bc, mk3(pos.x + 0.0f, pos.y + 0.0f, pos.z + 0.5f * vs), d001, c);
+    const float dp00 = trilinear_partial(hd, hp, bc, pos.x - 0.5f * vs, pos.y - 0.0f, pos.z - 0.0f);
+    const float d0p0 = trilinear_partial(hd, hp, bc, pos.x - 0.0f, pos.y - 0.5f * vs, pos.z - 0.0f);
+    const float d00p = trilinear_partial(hd, hp, bc, pos.x - 0.0f, pos.y - 0.0f, pos.z - 0.5f * vs);
+    const float d100 = trilinear_partial(hd, hp, bc, pos.x + 0.5f * vs, pos.y + 0.0f, pos.z + 0.0f);
+    const float d010 = trilinear_partial(hd, hp, bc, pos.x + 0.0f, pos.y + 0.5f * vs, pos.z + 0.0f);
+    const float d001 = trilinear_partial(hd, hp, bc, pos.x + 0.0f, pos.y + 0.0f, pos.z + 0.5f * vs);
     const F3 g = mk3((dp00 - d100) / vs, (d0p0 - d010) / vs, (d00p - d001) / vs);
     const float l = sqrtf(dot3(g, g));
     if (l == 0.0f) return mk3(0.0f, 0.0f, 0.0f);
     return mk3(-g.x / l, -g.y / l, -g.z / l);
 }
 
+constexpr int kLookahead = 4;
+
+template <bool GRADIENTS>
 __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd,
                                                 VhDepthCameraParams cp, VhRayCastParams rp)
 {
@@ -497,49 +575,105 @@ __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, 
     const float minInterval = rp.m_minDepth, maxInterval = rp.m_maxDepth;
     const bool run = !(minInterval == 0.0f || minInterval == mi) && !(maxInterval == 0.0f || maxInterval == mi);
     if (run) {
+        const float depthToRayLength = 1.0f / camDir.z;
+        const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
+        const float inc = rp.m_rayIncrement;
+        const float vs = hp.m_virtualVoxelSize;
+        const float halfVoxel = vs / 2.0f;
+        BlockCache bc;
+        cache_init(bc);
+
+        // march state (traverseCoarseGridSimpleSampleAll)
+        float rcur = depthToRayLength * fmaxf(rp.m_minDepth, minInterval); // rayCurrent
         float lastSdf = 0.0f, lastAlpha = 0.0f;
         bool lastValid = false;
-        const float depthToRayLength = 1.0f / camDir.z;
-        float rayCurrent = depthToRayLength * fmaxf(rp.m_minDepth, minInterval);
-        const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
-        BlockCache bc;
-        bc.valid = false; bc.bx = bc.by = bc.bz = 0; bc.ptr = VH_FREE_ENTRY;
+        uint32_t maybeMask = 0u; // look-ahead: bit i = first tap of sample rcur + i*inc may have a block
+        int li = kLookahead;     // position inside the look-ahead window (== kLookahead: refill)
+        // bisection state (findIntersectionBisection)
+        bool bisect = false;
+        int bIter = 0;
+        float ba = 0.0f, baDist = 0.0f, bb = 0.0f, bbDist = 0.0f, bcur = 0.0f, mDist = 0.0f;
 
 #pragma unroll 1
-        while (rayCurrent < rayEnd) {
-            const F3 p = mk3(worldCamPos.x + rayCurrent * worldDir.x, worldCamPos.y + rayCurrent * worldDir.y, worldCamPos.z + rayCurrent * worldDir.z);
-            float dist;
-            uint32_t color;
-            if (trilinear(hd, hp, bc, p, dist, color)) {
-                if (lastValid && lastSdf > 0.0f && dist < 0.0f) {
-                    float alpha = 0.0f;
-                    uint32_t color2 = 0;
-                    const bool ok = intersect_bisection(hd, hp, bc, worldCamPos, worldDir, lastSdf, lastAlpha, dist, rayCurrent, alpha, color2);
-                    if (ok && fabsf(lastSdf - dist) < rp.m_thresSampleDist) {
-                        if (fabsf(dist) < rp.m_thresDist) {
-                            const float depth = alpha / depthToRayLength;
-                            outDepth = depth;
-                            const F3 sk = depth_to_skeleton(cp, x, y, depth);
-                            outDepth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
-                            outColor = make_float4((float)(color2 & 0xffu) / 255.f, (float)((color2 >> 8) & 0xffu) / 255.f,
-                                                   (float)((color2 >> 16) & 0xffu) / 255.f, 1.0f);
-                            if (rp.m_useGradients) {
-                                const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
-                                const F3 g = gradient_for_point(hd, hp, bc, iso);
-                                const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
-                                outNormal = make_float4(n.x, n.y, n.z, 1.0f);
-                            }
-                            break;
-                        }
+        while (true) {
+            float t;
+            if (!bisect) {
+                if (li == kLookahead) {
+                    float r = rcur; // same sequence of additions the march performs
+                    maybeMask = 0u;
+#pragma unroll
+                    for (int i = 0; i < kLookahead; i++) {
+                        const int vx = world_to_vvp1((worldCamPos.x + r * worldDir.x) - halfVoxel, vs);
+                        const int vy = world_to_vvp1((worldCamPos.y + r * worldDir.y) - halfVoxel, vs);
+                        const int vz = world_to_vvp1((worldCamPos.z + r * worldDir.z) - halfVoxel, vs);
+                        const I3 b = mki3(vvp_to_block1(vx), vvp_to_block1(vy), vvp_to_block1(vz));
+                        maybeMask |= (bucket_maybe_occupied(hd, hash_pos(hp.m_hashNumBuckets, b)) ? 1u : 0u) << i;
+                        r += inc;
                     }
+                    li = 0;
                 }
-                lastSdf = dist;
-                lastAlpha = rayCurrent;
-                lastValid = true;
+                if (!(rcur < rayEnd)) break;
+                if (!((maybeMask >> li) & 1u)) { // first tap has no block: the sample is invalid
+                    lastValid = false;
+                    li++;
+                    rcur += inc;
+                    continue;
+                }
+                t = rcur;
             } else {
-                lastValid = false;
+                bcur = ba + (baDist / (baDist - bbDist)) * (bb - ba); // findIntersectionLinear :140-143
+                t = bcur;
             }
-            rayCurrent += rp.m_rayIncrement;
+
+            float dist = 0.0f;
+            uint32_t color = 0u;
+            const bool ok = trilinear(hd, hp, bc, mk3(worldCamPos.x + t * worldDir.x, worldCamPos.y + t * worldDir.y, worldCamPos.z + t * worldDir.z), dist, color);
+
+            if (!bisect) {
+                if (ok && lastValid && lastSdf > 0.0f && dist < 0.0f) { // sign change: bisect [lastAlpha, rcur]
+                    bisect = true;
+                    bIter = 0;
+                    ba = lastAlpha; baDist = lastSdf; bb = rcur; bbDist = dist; mDist = dist;
+                    continue;
+                }
+                if (ok) { lastSdf = dist; lastAlpha = rcur; lastValid = true; }
+                else lastValid = false;
+                li++;
+                rcur += inc;
+            } else {
+                bool finished = false, success = false;
+                if (!ok) {
+                    finished = true;
+                } else {
+                    if (baDist * dist > 0.0f) { ba = bcur; baDist = dist; }
+                    else { bb = bcur; bbDist = dist; }
+                    bIter++;
+                    if (bIter == 3) { finished = true; success = true; }
+                }
+                if (finished) {
+                    bisect = false;
+                    if (success && fabsf(lastSdf - mDist) < rp.m_thresSampleDist && fabsf(mDist) < rp.m_thresDist) {
+                        const float alpha = bcur;
+                        const float depth = alpha / depthToRayLength;
+                        outDepth = depth;
+                        const F3 sk = depth_to_skeleton(cp, x, y, depth);
+                        outDepth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
+                        outColor = make_float4((float)(color & 0xffu) / 255.f, (float)((color >> 8) & 0xffu) / 255.f,
+                                               (float)((color >> 16) & 0xffu) / 255.f, 1.0f);
+                        if (GRADIENTS) {
+                            const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
+                            const F3 g = gradient_for_point(hd, hp, bc, iso);
+                            const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
+                            outNormal = make_float4(n.x, n.y, n.z, 1.0f);
+                        }
+                        break;
+                    }
+                    // no accepted hit: the march sample becomes the last sample and the march goes on
+                    lastSdf = mDist; lastAlpha = rcur; lastValid = true;
+                    li++;
+                    rcur += inc;
+                }
+            }
         }
     }
     rd.d_depth[pix] = outDepth;
@@ -831,7 +965,8 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
     if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth) return VH_ERR_BAD_ARGUMENT;
     const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
     if (tiles == 0) return VH_OK;
-    k_render<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp);
+    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp);
+    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp);
     return vh_last_launch_error();
 }
 
