@@ -128,6 +128,12 @@ enum { VH_OP_ALLOC = 0, VH_OP_DELETE = 1, VH_OP_INSERT = 2, VH_OP_LOOKUP = 3, VH
 int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_t* d_ops, int32_t* d_results,
                       uint32_t n, vhStream_t stream);
 
+/* Self-check of the two exact shortcuts the ray caster uses: division by the
+ * voxel size through a reciprocal with two correction steps, and modulo by the
+ * bucket count through a multiply-shift.  d_mismatches[0] / [1] = number of
+ * operands (of n pseudo-random ones) where the shortcut differs from `/` / `%`. */
+int vh_debug_check_fast_math(float divisor, uint32_t modulus, uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream);
+
 /* ---- host classes (opaque handles over the C++ classes of include/vh.hpp) ---- */
 typedef struct VhSceneRep VhSceneRep;   /* CUDASceneRepHashSDF,   DSC/CUDASceneRepHashSDF.h:28 */
 typedef struct VhRayCast VhRayCast;     /* CUDARayCastSDF,        DSC/CUDARayCastSDF.h:13 */

@@ -105,3 +105,15 @@ def test_raycast_with_gradients(E, oracle_lib):
     got, want = r.download(), o.render(poses[-1])
     assert_maps_equal(got, want, "gradients")
     assert (got["normals"][..., 3] == 1.0).sum() > 500
+
+
+@pytest.mark.parametrize("voxel,buckets", [(0.04, 500000), (0.01, 2000000), (0.02, 1 << 18), (0.004, 1 << 14), (0.035, 7)])
+def test_exact_shortcuts(vh, voxel, buckets):
+    """div_exact == `/` and umod_fast == `%` bit for bit on 16 M pseudo-random operands"""
+    import ctypes as C
+    from voxelhashing_amd.lib import DeviceBuffer, check
+    buf = DeviceBuffer(8)
+    check(vh.vh_debug_check_fast_math(C.c_float(voxel), buckets, 1 << 24, 1234567, buf.ptr, None), "check")
+    mism = buf.download(np.uint32)
+    assert mism[0] == 0, f"div_exact differs from IEEE division on {mism[0]} operands"
+    assert mism[1] == 0, f"umod_fast differs from % on {mism[1]} operands"

@@ -423,50 +423,55 @@ VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
     return *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]);
 }
 
-// trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116.
+// trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116, for tap
+// voxel coordinates (x0..z1) the caller has already resolved.
 // Returns false exactly when the reference does (some tap, in tap order, has
 // weight 0 -- a missing block yields the zero voxel); `dist` is then undefined
 // (the reference leaves a partial sum that only gradientForPoint can observe:
-// see trilinear_partial below).
-VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, F3 pos, float& dist, uint32_t& colorOut)
+// see trilinear_partial below).  The colour is accumulated only on request:
+// the reference computes it for every sample but reads it only from the last
+// bisection sample (RayCastSDFUtil.h:231,241).
+template <bool COLOR>
+VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, int x0, int y0, int z0, int x1, int y1, int z1,
+                   F3 pos, float rvs, float& dist, uint32_t& colorOut)
 {
     const float vs = hp.m_virtualVoxelSize;
-    const float oSet = vs;
-    const float h = oSet / 2.0f;
-    const F3 pd = mk3(pos.x - h, pos.y - h, pos.z - h);
-
-    const int x0 = world_to_vvp1(pd.x, vs), y0 = world_to_vvp1(pd.y, vs), z0 = world_to_vvp1(pd.z, vs);
-    const int x1 = world_to_vvp1(pd.x + oSet, vs), y1 = world_to_vvp1(pd.y + oSet, vs), z1 = world_to_vvp1(pd.z + oSet, vs);
     const int bxa = vvp_to_block1(x0), bya = vvp_to_block1(y0), bza = vvp_to_block1(z0);
     const int bxb = vvp_to_block1(x1), byb = vvp_to_block1(y1), bzb = vvp_to_block1(z1);
     // bit a of `straddle`: the tap pair along axis a lies in two different blocks
     const uint32_t straddle = (bxb != bxa ? 1u : 0u) | (byb != bya ? 2u : 0u) | (bzb != bza ? 4u : 0u);
 
     // block pointer per tap combo (bit0 = x1, bit1 = y1, bit2 = z1); one probe per DISTINCT block
-    int p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
-    uint32_t need = 0xffu;
-#pragma unroll 1
-    while (need) {
-        const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
-        const int p = cached_lookup(hd, hp, bc, (k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
-        if (p == VH_FREE_ENTRY) return false; // that tap reads the zero voxel (weight 0)
-        const uint32_t km = k & straddle;
-        if (((0u) & straddle) == km) p0 = p;
-        if (((1u) & straddle) == km) p1 = p;
-        if (((2u) & straddle) == km) p2 = p;
-        if (((3u) & straddle) == km) p3 = p;
-        if (((4u) & straddle) == km) p4 = p;
-        if (((5u) & straddle) == km) p5 = p;
-        if (((6u) & straddle) == km) p6 = p;
-        if (((7u) & straddle) == km) p7 = p;
-        uint32_t same = 0u;
+    int p0 = cached_lookup(hd, hp, bc, bxa, bya, bza);
+    if (p0 == VH_FREE_ENTRY) return false; // the first tap reads the zero voxel (weight 0)
+    int p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
+    if (straddle) {
+        uint32_t need = 0xfeu; // combos whose block differs from combo 0 still need a pointer
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) same |= (((j & straddle) == km) ? 1u : 0u) << j;
-        need &= ~same;
+        for (uint32_t j = 1; j < 8u; j++)
+            if ((j & straddle) == 0u) need &= ~(1u << j);
+#pragma unroll 1
+        while (need) {
+            const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
+            const int p = cached_lookup(hd, hp, bc, (k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
+            if (p == VH_FREE_ENTRY) return false;
+            const uint32_t km = k & straddle;
+            if (((1u) & straddle) == km) p1 = p;
+            if (((2u) & straddle) == km) p2 = p;
+            if (((3u) & straddle) == km) p3 = p;
+            if (((4u) & straddle) == km) p4 = p;
+            if (((5u) & straddle) == km) p5 = p;
+            if (((6u) & straddle) == km) p6 = p;
+            if (((7u) & straddle) == km) p7 = p;
+            uint32_t same = 0u;
+#pragma unroll
+            for (uint32_t j = 1; j < 8u; j++) same |= (((j & straddle) == km) ? 1u : 0u) << j;
+            need &= ~same;
+        }
     }
 
-    const int lx0 = local1(x0), ly0 = local1(y0), lz0 = local1(z0);
-    const int lx1 = local1(x1), ly1 = local1(y1), lz1 = local1(z1);
+    const int lx0 = x0 & 7, ly0 = y0 & 7, lz0 = z0 & 7; // = local1(): two's complement & 7 is the non-negative remainder
+    const int lx1 = x1 & 7, ly1 = y1 & 7, lz1 = z1 & 7;
     // the eight voxels, in flight together (reference tap order 000,100,010,001,110,011,101,111)
     const Vox v000 = unpack_vox(load_voxel(hd, p0, lx0, ly0, lz0));
     const Vox v100 = unpack_vox(load_voxel(hd, p1, lx1, ly0, lz0));
@@ -476,30 +481,31 @@ VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc,
     const Vox v011 = unpack_vox(load_voxel(hd, p6, lx0, ly1, lz1));
     const Vox v101 = unpack_vox(load_voxel(hd, p5, lx1, ly0, lz1));
     const Vox v111 = unpack_vox(load_voxel(hd, p7, lx1, ly1, lz1));
-    if (v000.weight() == 0u || v100.weight() == 0u || v010.weight() == 0u || v001.weight() == 0u ||
-        v110.weight() == 0u || v011.weight() == 0u || v101.weight() == 0u || v111.weight() == 0u)
-        return false;
+    // weight byte == 0 for any tap <=> min over the taps of (cw >> 24) == 0
+    const uint32_t wmin = min(min(min(v000.cw, v100.cw), min(v010.cw, v001.cw)), min(min(v110.cw, v011.cw), min(v101.cw, v111.cw)));
+    if ((wmin >> 24) == 0u) return false;
 
-    const float fx = pos.x / vs, fy = pos.y / vs, fz = pos.z / vs;
+    const float fx = div_exact(pos.x, vs, rvs), fy = div_exact(pos.y, vs, rvs), fz = div_exact(pos.z, vs, rvs);
     const float wx = fx - floorf(fx), wy = fy - floorf(fy), wz = fz - floorf(fz);
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
     float d = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
 #define VH_ACC(V, WX, WY, WZ)                                           \
     {                                                                   \
         const float s = (WX) * (WY) * (WZ);                             \
         d += s * (V).sdf;                                               \
-        cr += s * (float)(V).r(); cg += s * (float)(V).g(); cb += s * (float)(V).b(); \
+        if (COLOR) { cr += s * (float)(V).r(); cg += s * (float)(V).g(); cb += s * (float)(V).b(); } \
     }
-    VH_ACC(v000, 1.0f - wx, 1.0f - wy, 1.0f - wz)
-    VH_ACC(v100, wx, 1.0f - wy, 1.0f - wz)
-    VH_ACC(v010, 1.0f - wx, wy, 1.0f - wz)
-    VH_ACC(v001, 1.0f - wx, 1.0f - wy, wz)
-    VH_ACC(v110, wx, wy, 1.0f - wz)
-    VH_ACC(v011, 1.0f - wx, wy, wz)
-    VH_ACC(v101, wx, 1.0f - wy, wz)
+    VH_ACC(v000, ux, uy, uz)
+    VH_ACC(v100, wx, uy, uz)
+    VH_ACC(v010, ux, wy, uz)
+    VH_ACC(v001, ux, uy, wz)
+    VH_ACC(v110, wx, wy, uz)
+    VH_ACC(v011, ux, wy, wz)
+    VH_ACC(v101, wx, uy, wz)
     VH_ACC(v111, wx, wy, wz)
 #undef VH_ACC
     dist = d;
-    colorOut = (uint32_t)f2uc(cr) | ((uint32_t)f2uc(cg) << 8) | ((uint32_t)f2uc(cb) << 16);
+    if (COLOR) colorOut = (uint32_t)f2uc(cr) | ((uint32_t)f2uc(cg) << 8) | ((uint32_t)f2uc(cb) << 16);
     return true;
 }
 
@@ -549,11 +555,40 @@ VHD F3 gradient_for_point(const VhHashData& hd, const VhHashParams& hp, const Bl
     return mk3(-g.x / l, -g.y / l, -g.z / l);
 }
 
-constexpr int kLookahead = 4;
+// Tap voxel coordinates of the sample at ray parameter t.
+// Division-free when possible: q ~ pos/voxel is evaluated approximately (one fma per axis).  The lower tap
+// of an axis is round_half_away((pos - voxel/2)/voxel) = floor(pos/voxel) and the upper tap is that + 1
+// whenever pos/voxel is not within rounding distance of an integer.  With u = 2^-24 and Q a bound on
+// |pos/voxel| along the ray, the approximate q is off by <= 3uQ and the reference's own quotient (two
+// products, two sums, a division and the +-0.5) by <= 5uQ; a fractional part at least 32uQ away from 0
+// and 1 therefore settles both taps.  Anything closer takes the exact path with the reference's
+// arithmetic.  The decision is made per WAVE-iteration in practice (one uncertain lane sends the whole
+// wave through the exact code), hence the tight margin: ~0.3 % per lane at Q = 256.
+struct RayQ {
+    F3 cam, dir;   // exact ray (world)
+    F3 camq, dirq; // ~ cam/voxel, dir/voxel
+    float vs, rvs, halfVoxel;
+    float certLim; // 0.5 - margin, negative if the approximation must not be used
+};
+
+VHD void tap_coords(const RayQ& rq, float t, int& x0, int& y0, int& z0, int& x1, int& y1, int& z1)
+{
+    const float qx = __fmaf_rn(t, rq.dirq.x, rq.camq.x), qy = __fmaf_rn(t, rq.dirq.y, rq.camq.y), qz = __fmaf_rn(t, rq.dirq.z, rq.camq.z);
+    const float gx = floorf(qx), gy = floorf(qy), gz = floorf(qz);
+    const float dev = fmaxf(fmaxf(fabsf((qx - gx) - 0.5f), fabsf((qy - gy) - 0.5f)), fabsf((qz - gz) - 0.5f));
+    if (dev < rq.certLim) {
+        x0 = (int)gx; y0 = (int)gy; z0 = (int)gz;
+        x1 = x0 + 1; y1 = y0 + 1; z1 = z0 + 1;
+    } else {
+        const F3 pd = mk3((rq.cam.x + t * rq.dir.x) - rq.halfVoxel, (rq.cam.y + t * rq.dir.y) - rq.halfVoxel, (rq.cam.z + t * rq.dir.z) - rq.halfVoxel);
+        x0 = world_to_vvp1_rb(pd.x, rq.vs, rq.rvs); y0 = world_to_vvp1_rb(pd.y, rq.vs, rq.rvs); z0 = world_to_vvp1_rb(pd.z, rq.vs, rq.rvs);
+        x1 = world_to_vvp1_rb(pd.x + rq.vs, rq.vs, rq.rvs); y1 = world_to_vvp1_rb(pd.y + rq.vs, rq.vs, rq.rvs); z1 = world_to_vvp1_rb(pd.z + rq.vs, rq.vs, rq.rvs);
+    }
+}
 
 template <bool GRADIENTS>
 __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd,
-                                                VhDepthCameraParams cp, VhRayCastParams rp)
+                                                VhDepthCameraParams cp, VhRayCastParams rp, HashMod hm)
 {
     const uint32_t lane = lane_id();
     const uint32_t W = rp.m_width, H = rp.m_height;
@@ -567,6 +602,11 @@ __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, 
     const float mi = minf();
     float outDepth = mi;
     float4 outDepth4 = make_float4(mi, mi, mi, mi), outNormal = outDepth4, outColor = outDepth4;
+#ifdef VH_RENDER_STATS
+    const long long statT0 = clock64();
+    const long long statR0 = wall_clock64();
+    float statTri = 0.0f, statIter = 0.0f;
+#endif
 
     const F3 camDir = normalize3(depth_to_skeleton(cp, x, y, proj_to_cam_z(cp, 1.0f)));
     const F3 worldCamPos = mat_mul_p(rp.m_viewMatrixInverse, mk3(0.0f, 0.0f, 0.0f));
@@ -578,104 +618,105 @@ __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, 
         const float depthToRayLength = 1.0f / camDir.z;
         const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
         const float inc = rp.m_rayIncrement;
-        const float vs = hp.m_virtualVoxelSize;
-        const float halfVoxel = vs / 2.0f;
+        RayQ rq;
+        rq.cam = worldCamPos; rq.dir = worldDir;
+        rq.vs = hp.m_virtualVoxelSize;
+        rq.rvs = 1.0f / rq.vs; // IEEE reciprocal for div_exact
+        rq.halfVoxel = rq.vs / 2.0f;
+        rq.camq = mk3(worldCamPos.x * rq.rvs, worldCamPos.y * rq.rvs, worldCamPos.z * rq.rvs);
+        rq.dirq = mk3(worldDir.x * rq.rvs, worldDir.y * rq.rvs, worldDir.z * rq.rvs);
+        {
+            // Q bounds |pos/voxel| for every sample of this ray (march and bisection parameters are <= rayEnd)
+            const float Q = 1.0f + (fabsf(rq.camq.x) + fabsf(rq.camq.y) + fabsf(rq.camq.z)) +
+                            fabsf(rayEnd) * (fabsf(rq.dirq.x) + fabsf(rq.dirq.y) + fabsf(rq.dirq.z));
+            const float margin = Q * (32.0f / 16777216.0f);
+            rq.certLim = (Q < 65536.0f) ? 0.5f - margin : -1.0f; // NaN/inf Q compare false: exact path
+        }
         BlockCache bc;
         cache_init(bc);
 
-        // march state (traverseCoarseGridSimpleSampleAll)
+        // traverseCoarseGridSimpleSampleAll, DSC/RayCastSDFUtil.h:198-262.  Written as march-until-sign-change /
+        // bisect / resume so that the lanes of a wave run their bisections together instead of interleaving
+        // them with other lanes' marching; each ray's own sequence of samples is the reference's.
         float rcur = depthToRayLength * fmaxf(rp.m_minDepth, minInterval); // rayCurrent
         float lastSdf = 0.0f, lastAlpha = 0.0f;
-        bool lastValid = false;
-        uint32_t maybeMask = 0u; // look-ahead: bit i = first tap of sample rcur + i*inc may have a block
-        int li = kLookahead;     // position inside the look-ahead window (== kLookahead: refill)
-        // bisection state (findIntersectionBisection)
-        bool bisect = false;
-        int bIter = 0;
-        float ba = 0.0f, baDist = 0.0f, bb = 0.0f, bbDist = 0.0f, bcur = 0.0f, mDist = 0.0f;
+        int lastValid = 0; // flags live in VGPRs: on this kernel the scalar unit (one per CU) is the scarce resource
 
 #pragma unroll 1
-        while (true) {
-            float t;
-            if (!bisect) {
-                if (li == kLookahead) {
-                    float r = rcur; // same sequence of additions the march performs
-                    maybeMask = 0u;
-#pragma unroll
-                    for (int i = 0; i < kLookahead; i++) {
-                        const int vx = world_to_vvp1((worldCamPos.x + r * worldDir.x) - halfVoxel, vs);
-                        const int vy = world_to_vvp1((worldCamPos.y + r * worldDir.y) - halfVoxel, vs);
-                        const int vz = world_to_vvp1((worldCamPos.z + r * worldDir.z) - halfVoxel, vs);
-                        const I3 b = mki3(vvp_to_block1(vx), vvp_to_block1(vy), vvp_to_block1(vz));
-                        maybeMask |= (bucket_maybe_occupied(hd, hash_pos(hp.m_hashNumBuckets, b)) ? 1u : 0u) << i;
-                        r += inc;
-                    }
-                    li = 0;
-                }
-                if (!(rcur < rayEnd)) break;
-                if (!((maybeMask >> li) & 1u)) { // first tap has no block: the sample is invalid
-                    lastValid = false;
-                    li++;
-                    rcur += inc;
-                    continue;
-                }
-                t = rcur;
-            } else {
-                bcur = ba + (baDist / (baDist - bbDist)) * (bb - ba); // findIntersectionLinear :140-143
-                t = bcur;
-            }
-
-            float dist = 0.0f;
-            uint32_t color = 0u;
-            const bool ok = trilinear(hd, hp, bc, mk3(worldCamPos.x + t * worldDir.x, worldCamPos.y + t * worldDir.y, worldCamPos.z + t * worldDir.z), dist, color);
-
-            if (!bisect) {
-                if (ok && lastValid && lastSdf > 0.0f && dist < 0.0f) { // sign change: bisect [lastAlpha, rcur]
-                    bisect = true;
-                    bIter = 0;
-                    ba = lastAlpha; baDist = lastSdf; bb = rcur; bbDist = dist; mDist = dist;
-                    continue;
-                }
-                if (ok) { lastSdf = dist; lastAlpha = rcur; lastValid = true; }
-                else lastValid = false;
-                li++;
+        for (;;) {
+            // ---- A: skip samples whose first tap has no block (they are invalid: weight 0 at the first tap).
+            // Tight loop: the lanes of a wave leave it at their next sample with a first tap, or at the end.
+            int x0, y0, z0, x1, y1, z1;
+            int skipped = 0;
+#pragma unroll 1
+            while (rcur < rayEnd) {
+#ifdef VH_RENDER_STATS
+                statIter += 1.0f;
+#endif
+                tap_coords(rq, rcur, x0, y0, z0, x1, y1, z1);
+                // x >> 3 = vvp_to_block1(x): the arithmetic shift floors
+                if (bucket_maybe_occupied(hd, hash_pos_fast(hm, mki3(x0 >> 3, y0 >> 3, z0 >> 3)))) break;
+                skipped = 1;
                 rcur += inc;
-            } else {
-                bool finished = false, success = false;
-                if (!ok) {
-                    finished = true;
-                } else {
-                    if (baDist * dist > 0.0f) { ba = bcur; baDist = dist; }
-                    else { bb = bcur; bbDist = dist; }
-                    bIter++;
-                    if (bIter == 3) { finished = true; success = true; }
-                }
-                if (finished) {
-                    bisect = false;
-                    if (success && fabsf(lastSdf - mDist) < rp.m_thresSampleDist && fabsf(mDist) < rp.m_thresDist) {
-                        const float alpha = bcur;
-                        const float depth = alpha / depthToRayLength;
-                        outDepth = depth;
-                        const F3 sk = depth_to_skeleton(cp, x, y, depth);
-                        outDepth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
-                        outColor = make_float4((float)(color & 0xffu) / 255.f, (float)((color >> 8) & 0xffu) / 255.f,
-                                               (float)((color >> 16) & 0xffu) / 255.f, 1.0f);
-                        if (GRADIENTS) {
-                            const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
-                            const F3 g = gradient_for_point(hd, hp, bc, iso);
-                            const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
-                            outNormal = make_float4(n.x, n.y, n.z, 1.0f);
-                        }
-                        break;
-                    }
-                    // no accepted hit: the march sample becomes the last sample and the march goes on
-                    lastSdf = mDist; lastAlpha = rcur; lastValid = true;
-                    li++;
-                    rcur += inc;
-                }
             }
+            if (!(rcur < rayEnd)) break; // ray left the depth range
+            lastValid = skipped ? 0 : lastValid;
+
+            // ---- B: full sample at rcur
+#ifdef VH_RENDER_STATS
+            statTri += 1.0f;
+#endif
+            float dist = 0.0f;
+            uint32_t colorUnused = 0u;
+            const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
+            const bool ok = trilinear<false>(hd, hp, bc, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
+
+            if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) {
+                // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur]
+                float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
+                uint32_t color2 = 0u;
+                bool success = true;
+#pragma unroll 1
+                for (int i = 0; i < 3; i++) {
+#ifdef VH_RENDER_STATS
+                    statIter += 1.0f; statTri += 1.0f;
+#endif
+                    c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
+                    int cx0, cy0, cz0, cx1, cy1, cz1;
+                    tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
+                    const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
+                    float cDist = 0.0f;
+                    if (!trilinear<true>(hd, hp, bc, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
+                    if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
+                    else { b = c; bDist = cDist; }
+                }
+                if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
+                    const float alpha = c;
+                    const float depth = alpha / depthToRayLength;
+                    outDepth = depth;
+                    const F3 sk = depth_to_skeleton(cp, x, y, depth);
+                    outDepth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
+                    outColor = make_float4((float)(color2 & 0xffu) / 255.f, (float)((color2 >> 8) & 0xffu) / 255.f,
+                                           (float)((color2 >> 16) & 0xffu) / 255.f, 1.0f);
+                    if (GRADIENTS) {
+                        const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
+                        const F3 g = gradient_for_point(hd, hp, bc, iso);
+                        const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
+                        outNormal = make_float4(n.x, n.y, n.z, 1.0f);
+                    }
+                    break;
+                }
+                // no accepted hit: the march sample becomes the last sample and the march goes on (:248-252)
+            }
+            lastSdf = ok ? dist : lastSdf;
+            lastAlpha = ok ? rcur : lastAlpha;
+            lastValid = ok ? 1 : 0;
+            rcur += inc;
         }
     }
+#ifdef VH_RENDER_STATS
+    outNormal = make_float4((float)(clock64() - statT0), statTri, statIter, (float)(wall_clock64() - statR0));
+#endif
     rd.d_depth[pix] = outDepth;
     reinterpret_cast<float4*>(rd.d_depth4)[pix] = outDepth4;
     reinterpret_cast<float4*>(rd.d_normals)[pix] = outNormal;
@@ -849,7 +890,49 @@ __global__ void k_debug_hash_ops(VhHashData hd, VhHashParams hp, const int32_t* 
     }
 }
 
+// checks div_exact against `/` and umod_fast against `%` on pseudo-random operands
+__global__ __launch_bounds__(256) void k_check_fast_math(float b, HashMod hm, uint32_t n, uint32_t seed, uint32_t* mismatches)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // xorshift-multiply scramble of (seed, i)
+    uint32_t s = (i + 1u) * 2654435761u ^ seed;
+    s ^= s >> 15; s *= 2246822519u; s ^= s >> 13; s *= 3266489917u; s ^= s >> 16;
+    uint32_t u = s * 747796405u + 2891336453u;
+    // dividend: mostly scene-scale positions, some raw bit patterns (any finite magnitude)
+    float a;
+    if ((i & 7u) == 7u) {
+        a = __uint_as_float(u);
+        const uint32_t ex = (u >> 23) & 0xffu;
+        if (ex == 0xffu || ex < 0x10u || ex > 0xe8u) a = (float)(int)u * 1.0e-6f; // keep a and a/b normal
+    } else {
+        a = ((float)(int)u) * (1.0f / 2147483648.0f) * (((i >> 3) & 1u) ? 400.0f : 8.0f);
+    }
+    const float rb = 1.0f / b;
+    const float q0 = a / b, q1 = div_exact(a, b, rb);
+    if (__float_as_uint(q0) != __float_as_uint(q1) && !(q0 == 0.0f && q1 == 0.0f)) atomicAdd(&mismatches[0], 1u);
+    if ((s % hm.d) != umod_fast(s, hm)) atomicAdd(&mismatches[1], 1u);
+    if ((u % hm.d) != umod_fast(u, hm)) atomicAdd(&mismatches[1], 1u);
+    if (i < 64u) { // extremes of the unsigned range
+        const uint32_t e = 0xffffffffu - i;
+        if ((e % hm.d) != umod_fast(e, hm)) atomicAdd(&mismatches[1], 1u);
+        if ((i % hm.d) != umod_fast(i, hm)) atomicAdd(&mismatches[1], 1u);
+    }
+}
+
 inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// multiply-shift constants of umod_fast for divisor d >= 2
+inline HashMod make_hash_mod(uint32_t d)
+{
+    HashMod k;
+    k.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < (uint64_t)d) l++;
+    k.m = (uint32_t)((((1ull << 32) * ((1ull << l) - (uint64_t)d)) / d) + 1ull);
+    k.sh = l - 1;
+    return k;
+}
 
 } // namespace
 
@@ -965,8 +1048,10 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
     if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth) return VH_ERR_BAD_ARGUMENT;
     const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
     if (tiles == 0) return VH_OK;
-    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp);
-    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp);
+    if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
+    const HashMod hm = make_hash_mod(hp->m_hashNumBuckets);
+    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm);
+    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm);
     return vh_last_launch_error();
 }
 
@@ -1042,6 +1127,15 @@ int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_
     if (!hd || !hp || !d_ops || !d_results) return VH_ERR_BAD_ARGUMENT;
     if (n == 0) return VH_OK;
     k_debug_hash_ops<<<1, 64, 0, (hipStream_t)stream>>>(*hd, *hp, d_ops, d_results, n);
+    return vh_last_launch_error();
+}
+
+int vh_debug_check_fast_math(float divisor, uint32_t modulus, uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream)
+{
+    if (!d_mismatches || modulus < 2 || !(divisor > 0.0f)) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipMemsetAsync(d_mismatches, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
+    if (n == 0) return VH_OK;
+    k_check_fast_math<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(divisor, make_hash_mod(modulus), n, seed, d_mismatches);
     return vh_last_launch_error();
 }
 
