@@ -408,11 +408,20 @@ VHD void cache_init(BlockCache& bc)
     bc.p0 = bc.p1 = VH_FREE_ENTRY;
 }
 
-VHD int cached_lookup(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, int bx, int by, int bz)
+// getHashEntryForSDFBlockPos (DSC/VoxelUtilHashSDF.h:424-468) behind a 2-entry per-ray cache.  A miss loads the
+// bucket's occupancy word and its first slot together (one round trip): a block sits in slot 0 unless two blocks
+// share the bucket, and an empty bucket proves absence; only the remaining cases walk the bucket.
+VHD int cached_lookup(const VhHashData& hd, const VhHashParams& hp, HashMod hm, BlockCache& bc, int bx, int by, int bz)
 {
     if (bc.v0 && bc.bx0 == bx && bc.by0 == by && bc.bz0 == bz) return bc.p0;
     if (bc.v1 && bc.bx1 == bx && bc.by1 == by && bc.bz1 == bz) return bc.p1;
-    const int p = lookup_ptr(hd, hp, mki3(bx, by, bz));
+    const uint32_t h = hash_pos_fast(hm, mki3(bx, by, bz));
+    const uint32_t word = hd.d_bucketBits[h >> 5];
+    const int4 q = load_quad(&hd.d_hash[h * VH_HASH_BUCKET_SIZE]);
+    int p;
+    if (quad_matches(q, mki3(bx, by, bz))) p = q.w;
+    else if (!((word >> (h & 31)) & 1u)) p = VH_FREE_ENTRY;
+    else p = lookup_ptr(hd, hp, mki3(bx, by, bz));
     bc.bx1 = bc.bx0; bc.by1 = bc.by0; bc.bz1 = bc.bz0; bc.p1 = bc.p0; bc.v1 = bc.v0;
     bc.bx0 = bx; bc.by0 = by; bc.bz0 = bz; bc.p0 = p; bc.v0 = true;
     return p;
@@ -432,7 +441,7 @@ VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 // the reference computes it for every sample but reads it only from the last
 // bisection sample (RayCastSDFUtil.h:231,241).
 template <bool COLOR>
-VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc, int x0, int y0, int z0, int x1, int y1, int z1,
+VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, HashMod hm, BlockCache& bc, int x0, int y0, int z0, int x1, int y1, int z1,
                    F3 pos, float rvs, float& dist, uint32_t& colorOut)
 {
     const float vs = hp.m_virtualVoxelSize;
@@ -442,7 +451,7 @@ VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc,
     const uint32_t straddle = (bxb != bxa ? 1u : 0u) | (byb != bya ? 2u : 0u) | (bzb != bza ? 4u : 0u);
 
     // block pointer per tap combo (bit0 = x1, bit1 = y1, bit2 = z1); one probe per DISTINCT block
-    int p0 = cached_lookup(hd, hp, bc, bxa, bya, bza);
+    int p0 = cached_lookup(hd, hp, hm, bc, bxa, bya, bza);
     if (p0 == VH_FREE_ENTRY) return false; // the first tap reads the zero voxel (weight 0)
     int p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
     if (straddle) {
@@ -453,7 +462,7 @@ VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, BlockCache& bc,
 #pragma unroll 1
         while (need) {
             const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
-            const int p = cached_lookup(hd, hp, bc, (k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
+            const int p = cached_lookup(hd, hp, hm, bc, (k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
             if (p == VH_FREE_ENTRY) return false;
             const uint32_t km = k & straddle;
             if (((1u) & straddle) == km) p1 = p;
@@ -529,7 +538,7 @@ __device__ __noinline__ float trilinear_partial(const VhHashData hd, const VhHas
         const int vx = world_to_vvp1(bx ? pd.x + oSet : pd.x, vs);
         const int vy = world_to_vvp1(by ? pd.y + oSet : pd.y, vs);
         const int vz = world_to_vvp1(bz ? pd.z + oSet : pd.z, vs);
-        const int p = cached_lookup(hd, hp, bc, vvp_to_block1(vx), vvp_to_block1(vy), vvp_to_block1(vz));
+        const int p = lookup_ptr(hd, hp, mki3(vvp_to_block1(vx), vvp_to_block1(vy), vvp_to_block1(vz)));
         if (p == VH_FREE_ENTRY) return d;
         const Vox v = unpack_vox(load_voxel(hd, p, local1(vx), local1(vy), local1(vz)));
         if (v.weight() == 0u) return d;
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, 
             float dist = 0.0f;
             uint32_t colorUnused = 0u;
             const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
-            const bool ok = trilinear<false>(hd, hp, bc, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
+            const bool ok = trilinear<false>(hd, hp, hm, bc, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
 
             if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) {
                 // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur]
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, 
                     tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
                     const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
                     float cDist = 0.0f;
-                    if (!trilinear<true>(hd, hp, bc, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
+                    if (!trilinear<true>(hd, hp, hm, bc, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
                     if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
                     else { b = c; bDist = cDist; }
                 }
