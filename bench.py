@@ -143,6 +143,25 @@ class GpuWorkload:
         return s
 
 
+def run_timed(workload, warmup, steps, dist_mod, device, sync=lambda: None, after_warmup=lambda: None):
+    """the measurement contract: `warmup` untimed frames, then exactly `steps` frames bracketed by a barrier
+    and a device synchronisation on both sides; the elapsed time is the MAX over ranks and the unit count the
+    SUM over ranks (weak scaling: every rank runs its own `steps` frames).  -> (seconds, total frames)"""
+    workload.run(0, warmup)
+    sync()
+    after_warmup()
+    barrier(dist_mod)
+    sync()
+    t0 = time.perf_counter()
+    workload.run(warmup, warmup + steps)
+    sync()
+    barrier(dist_mod)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(dist_mod, elapsed, device)
+    total = sum_over_ranks(dist_mod, float(steps), device)
+    return elapsed, total
+
+
 def stage_bytes(cfg_hp, cp, n_occ, stage):
     """ALGORITHMIC bytes per launch (E = 20 B entry payload, V = 8 B voxel)"""
     W, H = cp.m_imageWidth, cp.m_imageHeight
@@ -195,26 +214,18 @@ def main():
 
     n_frames = args.warmup + args.steps
     wl = GpuWorkload(args.config, n_frames, rank, args)
+    pre = {}
 
-    # warmup (untimed)
-    wl.run(0, args.warmup)
-    torch.cuda.synchronize()
-    wl.timings()  # fold and discard warm-up stage times
-    pre = wl.timings()
+    def after_warmup():
+        torch.cuda.synchronize()
+        pre.update(wl.timings())  # fold the warm-up stage times: the timed region starts from here
 
-    barrier(dist_mod)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    wl.run(args.warmup, n_frames)
-    torch.cuda.synchronize()
-    barrier(dist_mod)
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist_mod, elapsed, dev)
+    elapsed, total_frames = run_timed(wl, args.warmup, args.steps, dist_mod, dev, sync=torch.cuda.synchronize,
+                                      after_warmup=after_warmup)
+    value = total_frames / elapsed
 
     post = wl.timings()
     n_occ = wl.scene.getNumOccupiedBlocks()
-    total_frames = sum_over_ranks(dist_mod, float(args.steps), dev)
-    value = total_frames / elapsed
 
     # per-stage device time inside the timed region (HIP events on the launch stream)
     stages = {}

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Generates the fixtures in this directory with the CPU oracle (oracle/).
+
+They are REGRESSION vectors produced by this repository's own oracle -- the
+reference ships no golden data for this path and cannot
+be run in this image -- so they pin the oracle against accidental edits and
+let the GPU path be checked without the oracle; they are not reference outputs.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from voxelhashing_amd import synth, vhtypes as T  # noqa: E402
+
+CASES = {
+    # name: (width, height, params, buckets, sdf blocks, scene, frame indices of a 100-frame orbit, gc, starve)
+    "s1_64x48_p4": (64, 48, "P4", 1 << 12, 1 << 10, "S1", [0, 1, 2, 3], True, 2),
+    "s1_48x36_p2_gradients": (48, 36, "P2", 1 << 12, 1 << 11, "S1", [10, 11], False, 15),
+}
+
+
+def run_case(name):
+    W, H, ps, nb, nblk, scene, frames, gc, starve = CASES[name]
+    hp = T.make_hash_params(nb, nblk, **synth.PARAM_SETS[ps])
+    cp = T.make_depth_camera_params(W, H)
+    rp = T.make_raycast_params(hp, cp, use_gradients=name.endswith("gradients"))
+    opt = T.make_scene_options(offline=True, gc=gc, starve=starve)
+    spheres, inside, radius = synth.scene(scene)
+    sc = O.OracleScene(hp, cp, rp, opt)
+    out = dict(width=W, height=H, params=ps, num_buckets=nb, num_sdf_blocks=nblk, scene=scene,
+               frames=np.array(frames), gc=gc, starve=starve, use_gradients=int(rp.m_useGradients))
+    last = None
+    for i, k in enumerate(frames):
+        pose = synth.orbit_pose(k, 100, radius)
+        depth, color = O.synth_frame(spheres, inside, pose, cp)
+        if last is not None:
+            r = sc.render(last)
+            for m in ("depth", "depth4", "normals", "colors"):
+                out[f"f{i}_ray_{m}"] = r[m]
+        sc.integrate(pose, depth, color)
+        s = sc.state()
+        out[f"f{i}_depth_in"] = depth
+        out[f"f{i}_positions"] = s["positions"]
+        out[f"f{i}_voxels"] = s["voxels"]
+        out[f"f{i}_heap_free"] = s["heap_free"]
+        out[f"f{i}_num_in_frustum"] = sc.hp.m_numOccupiedBlocks
+        last = pose
+    return out
+
+
+def main():
+    for name in CASES:
+        data = run_case(name)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(name, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

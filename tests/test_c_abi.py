@@ -1,0 +1,101 @@
+"""The drop-in boundary without a GPU: the library loads, exports every symbol
+include/vh_api.h declares, the ctypes mirrors have the C layouts, and argument
+validation works (no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from voxelhashing_amd import lib, vhtypes as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "vh_api.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(vh_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(lib.LIB_PATH), "run `python -m voxelhashing_amd.build` (or __graft_entry__.build())"
+    assert os.path.dirname(lib.LIB_PATH) == os.path.join(ROOT, "voxelhashing_amd")
+
+
+def test_every_declared_symbol_is_exported_and_prototyped():
+    names = declared_functions()
+    assert len(names) > 60
+    L = C.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in vh_api.h but not exported: {missing}"
+    assert sorted(lib.PROTOTYPES) == names, (set(names) ^ set(lib.PROTOTYPES))
+    lib.load()
+    assert b"gfx950" in lib.load().vh_version()
+
+
+def test_struct_layouts_match_the_c_header():
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "vh_types.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(VhHashEntry), sizeof(VhVoxel), sizeof(VhHashParams),
+         sizeof(VhDepthCameraParams), sizeof(VhRayCastParams), sizeof(VhHashData), sizeof(VhDepthCameraData),
+         sizeof(VhRayCastData), sizeof(VhSDFBlockDesc), sizeof(VhSceneOptions));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(VhHashParams, m_hashNumBuckets), offsetof(VhHashParams, m_virtualVoxelSize),
+         offsetof(VhHashParams, m_streamingVoxelExtents), offsetof(VhRayCastParams, m_width), offsetof(VhHashData, d_bucketCount));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split("\n")
+    sizes = [int(v) for v in out[0].split()]
+    want = [C.sizeof(t) for t in (T.HashEntry, T.Voxel, T.HashParams, T.DepthCameraParams, T.RayCastParams, T.HashData,
+                                  T.DepthCameraData, T.RayCastData, T.SDFBlockDesc, T.SceneOptions)]
+    assert sizes == want
+    assert sizes[:5] == [32, 8, 224, 32, 304]  # reference layouts
+    offs = [int(v) for v in out[1].split()]
+    assert offs == [T.HashParams.m_hashNumBuckets.offset, T.HashParams.m_virtualVoxelSize.offset,
+                    T.HashParams.m_streamingVoxelExtents.offset, T.RayCastParams.m_width.offset, T.HashData.d_bucketCount.offset]
+
+
+def test_argument_validation_without_gpu():
+    L = lib.load()
+    assert L.vh_reset(None, None, None) == 4  # VH_ERR_BAD_ARGUMENT
+    assert L.vh_alloc(None, None, None, None, None, -1, None) == 4
+    assert L.vh_render(None, None, None, None, None, None) == 4
+    assert L.vh_scene_rep_integrate(None, None, None, None, None) == 4
+    hp = T.make_hash_params(16, 16, 0.04)
+    hp.m_hashBucketSize = 7  # the bucket size is a compile-time constant of the path
+    hd = T.HashData()
+    assert L.vh_hash_data_alloc(C.byref(hd), C.byref(hp)) == 4
+    assert L.vh_error_string(4) == b"bad argument"
+    assert L.vh_error_string(1) == b"SDF block heap exhausted"
+
+
+def test_cpp_host_header_compiles_standalone():
+    """include/vh.hpp needs no HIP headers: a reference-side translation unit can include it"""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        open(src, "w").write('#include "vh.hpp"\nint main(){ vh::mat4f m = vh::mat4f(); (void)m; return sizeof(CUDASceneRepHashSDF) > 0 ? 0 : 1; }\n')
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "voxelhashing_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|libvh_oracle|vh_oracle\.h|vho_", txt):
+                    bad.append(f)
+    assert not bad, f"product files reference the oracle: {bad}"

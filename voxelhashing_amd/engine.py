@@ -319,3 +319,126 @@ class CUDASceneRepChunkGrid:
 
     def loadFromFile(self, filename, camPos, radius):
         check(self.L.vh_chunk_grid_load_from_file(self.handle, filename.encode(), f16(camPos), radius), "loadFromFile")
+
+
+class LauncherScene:
+    """HashData + the launcher-level C ABI (the twins of the reference's
+    extern "C" launchers, DepthSensingCUDA/Source/CUDASceneRepHashSDF.h:15-26 and
+    CUDASceneRepChunkGrid.h:142-146), one call per kernel, for tests that pin
+    each launcher on its own."""
+
+    def __init__(self, params, stream=None):
+        self.L = load()
+        self.stream = stream
+        self.hp = _copy_struct(params)
+        self.hd = T.HashData()
+        check(self.L.vh_hash_data_alloc(C.byref(self.hd), C.byref(self.hp)), "vh_hash_data_alloc")
+        self.reset()
+
+    def close(self):
+        if getattr(self, "hd", None) is not None and self.hd.d_hash:
+            self.L.vh_stream_synchronize(self.stream)
+            self.L.vh_hash_data_free(C.byref(self.hd))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_transform(self, transform, inverse):
+        self.hp.m_rigidTransform = T.mat16(transform)
+        self.hp.m_rigidTransformInverse = T.mat16(inverse)
+
+    def reset(self):
+        check(self.L.vh_reset(C.byref(self.hd), C.byref(self.hp), self.stream), "vh_reset")
+
+    def reset_mutex(self):
+        check(self.L.vh_reset_bucket_mutex(C.byref(self.hd), C.byref(self.hp), self.stream), "vh_reset_bucket_mutex")
+
+    def alloc(self, frame, cp, bitmask_ptr=None, lock_token=T.LOCK_ENTRY):
+        check(self.L.vh_alloc(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), bitmask_ptr, lock_token, self.stream), "vh_alloc")
+
+    def compactify(self, cp):
+        n = C.c_uint32()
+        check(self.L.vh_compactify(C.byref(self.hd), C.byref(self.hp), C.byref(cp), C.byref(n), self.stream), "vh_compactify")
+        self.hp.m_numOccupiedBlocks = n.value
+        return n.value
+
+    def integrate(self, frame, cp):
+        check(self.L.vh_integrate(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), self.stream), "vh_integrate")
+
+    def integrate_fused(self, frame, cp, flags, lock_token):
+        check(self.L.vh_integrate_fused(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), flags, lock_token, self.stream),
+              "vh_integrate_fused")
+
+    def starve(self):
+        check(self.L.vh_starve(C.byref(self.hd), C.byref(self.hp), self.stream), "vh_starve")
+
+    def gc_identify(self, cp):
+        check(self.L.vh_gc_identify(C.byref(self.hd), C.byref(self.hp), C.byref(cp), self.stream), "vh_gc_identify")
+
+    def gc_free(self, lock_token=T.LOCK_ENTRY):
+        check(self.L.vh_gc_free(C.byref(self.hd), C.byref(self.hp), lock_token, self.stream), "vh_gc_free")
+
+    def hash_ops(self, ops):
+        """ops: [n,5] int32 {op, x, y, z, arg} executed serially by one thread -> results[n]"""
+        ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 5)
+        d_ops = DeviceBuffer.from_numpy(ops, self.stream)
+        d_res = DeviceBuffer(4 * len(ops))
+        check(self.L.vh_debug_hash_ops(C.byref(self.hd), C.byref(self.hp), d_ops.ptr, d_res.ptr, len(ops), self.stream), "vh_debug_hash_ops")
+        return d_res.download(np.int32, len(ops), self.stream)
+
+    def stream_out(self, threads_per_part, start, radius, cam_pos, lock_token, capacity=4096):
+        """pass 1 + pass 2 -> (descs, blocks)"""
+        cnt = DeviceBuffer(4)
+        check(self.L.vh_memset(cnt.ptr, 0, 4, self.stream), "memset")
+        d_desc = DeviceBuffer(16 * capacity)
+        check(self.L.vh_stream_out_pass1(C.byref(self.hd), C.byref(self.hp), threads_per_part, start, C.c_float(radius), f16(cam_pos),
+                                         cnt.ptr, d_desc.ptr, capacity, lock_token, self.stream), "vh_stream_out_pass1")
+        n = int(cnt.download(np.uint32, 1, self.stream)[0])
+        assert n <= capacity
+        d_blocks = DeviceBuffer(4096 * max(n, 1))
+        check(self.L.vh_stream_out_pass2(C.byref(self.hd), C.byref(self.hp), d_desc.ptr, d_blocks.ptr, n, self.stream), "vh_stream_out_pass2")
+        descs = d_desc.download(T.DESC_DTYPE, n, self.stream)
+        blocks = d_blocks.download(T.VOXEL_DTYPE, n * T.SDF_BLOCK_VOXELS, self.stream).reshape(n, T.SDF_BLOCK_VOXELS)
+        return descs, blocks
+
+    def stream_in(self, descs, blocks, lock_token):
+        descs = np.ascontiguousarray(descs, dtype=T.DESC_DTYPE)
+        blocks = np.ascontiguousarray(blocks, dtype=T.VOXEL_DTYPE)
+        n = len(descs)
+        if n == 0:
+            return
+        d_desc, d_blocks = DeviceBuffer.from_numpy(descs, self.stream), DeviceBuffer.from_numpy(blocks, self.stream)
+        prev = int(download(self.hd.d_heapCounter, np.uint32, 1, self.stream)[0])
+        check(self.L.vh_stream_in_pass1(C.byref(self.hd), C.byref(self.hp), n, prev, d_desc.ptr, lock_token, self.stream), "vh_stream_in_pass1")
+        check(self.L.vh_stream_in_pass2(C.byref(self.hd), C.byref(self.hp), n, prev, d_desc.ptr, d_blocks.ptr, self.stream), "vh_stream_in_pass2")
+        new = np.array([prev - n], dtype=np.uint32)
+        check(self.L.vh_memcpy_h2d(self.hd.d_heapCounter, new.ctypes.data, 4, self.stream), "heapCounter")
+
+    def download(self, with_voxels=True):
+        hp, hd, s = self.hp, self.hd, self.stream
+        ne = hp.m_hashNumBuckets * T.HASH_BUCKET_SIZE
+        out = dict(
+            params=hp,
+            hash=download(hd.d_hash, T.HASH_ENTRY_DTYPE, ne, s),
+            heap=download(hd.d_heap, np.uint32, hp.m_numSDFBlocks, s),
+            heap_counter=int(download(hd.d_heapCounter, np.uint32, 1, s)[0]),
+            bucket_count=download(hd.d_bucketCount, np.uint32, hp.m_hashNumBuckets, s),
+            bucket_bits=download(hd.d_bucketBits, np.uint32, (hp.m_hashNumBuckets + 31) // 32, s),
+            state=download(hd.d_state, np.uint32, T.STATE_WORDS, s),
+            compactified=download(hd.d_hashCompactified, T.HASH_ENTRY_DTYPE, hp.m_numOccupiedBlocks, s),
+            decisions=download(hd.d_hashDecision, np.int32, hp.m_numOccupiedBlocks, s),
+        )
+        if with_voxels:
+            out["sdf_blocks"] = download(hd.d_SDFBlocks, T.VOXEL_DTYPE, hp.m_numSDFBlocks * T.SDF_BLOCK_VOXELS, s)
+        return out
+
+    def state(self, with_voxels=True):
+        d = self.download(with_voxels)
+        canonical.check_invariants(d["hash"], d["heap"], d["heap_counter"], self.hp, d.get("sdf_blocks"))
+        canonical.check_bucket_summary(d["hash"], d["bucket_count"], d["bucket_bits"], self.hp)
+        snap = canonical.snapshot(d["hash"], d.get("sdf_blocks"), d["heap"], d["heap_counter"], self.hp, with_voxels)
+        snap.update(compactified=d["compactified"], decisions=d["decisions"], raw=d)
+        return snap
