@@ -125,9 +125,10 @@ private:
     vhStream_t m_stream;
     unsigned int m_numIntegratedFrames;
     int32_t m_lockEpoch;
-    uint32_t* h_occupied;     // pinned: async read-back of d_hashCompactifiedCounter
-    void* m_occupiedEvent;    // hipEvent_t
-    bool m_occupiedPending;
+    uint32_t* h_occupied;     // mapped pinned word: the fused integrate kernel mirrors the block count here
+    void* m_occupiedEvent;    // device alias of h_occupied
+    bool m_occupiedPending;   // a frame was enqueued since the host value was last known exact
+    bool m_counterCleared;    // d_hashCompactifiedCounter is known to be 0 (k_alloc clears it)
     VhStageTimer* m_timer;
 };
 

@@ -59,14 +59,18 @@ int vh_reset(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream);
 int vh_reset_bucket_mutex(const VhHashData* hd, const VhHashParams* hp, vhStream_t stream);
 /* allocCUDA(HashData&, const HashParams&, const DepthCameraData&, const DepthCameraParams&,
  *           const unsigned int* d_bitMask)                      DSC/CUDASceneRepHashSDF.cu:245
- * d_bitMask may be NULL (streaming disabled). */
+ * d_bitMask may be NULL (streaming disabled).  Also clears d_hashCompactifiedCounter for the
+ * compaction that follows. */
 int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
              const VhDepthCameraParams* cp, const uint32_t* d_bitMask, int32_t lockToken, vhStream_t stream);
 /* unsigned compactifyHashAllInOneCUDA(HashData&, const HashParams&)  DSC/CUDASceneRepHashSDF.cu:361
  * The count lands in d_hashCompactifiedCounter.  numOccupied != NULL: blocking
- * read-back as the reference does; NULL: fully asynchronous. */
+ * read-back as the reference does; NULL: fully asynchronous.
+ * flags: VH_COMPACT_COUNTER_IS_ZERO = the caller guarantees the counter is already 0 (vh_alloc leaves it
+ * cleared), which saves the memset the reference issues (DSC/CUDASceneRepHashSDF.cu:367). */
+enum { VH_COMPACT_COUNTER_IS_ZERO = 1 };
 int vh_compactify(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp,
-                  uint32_t* numOccupied, vhStream_t stream);
+                  uint32_t* numOccupied, uint32_t flags, vhStream_t stream);
 /* integrateDepthMapCUDA(...)                                     DSC/CUDASceneRepHashSDF.cu:495
  * integrates hp->m_numOccupiedBlocks compactified blocks. */
 int vh_integrate(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
@@ -85,10 +89,12 @@ int vh_bind_input_depth_color_textures(const VhDepthCameraData* cam);
  * voxels (one read + one write per voxel instead of up to four kernels);
  * same results as the four launchers above in the reference's order
  * (CUDASceneRepHashSDF::integrateDepthMap + garbageCollect, DSC/CUDASceneRepHashSDF.h:317-339).
- * The block count is read on the device from d_hashCompactifiedCounter. */
+ * The block count is read on the device from d_hashCompactifiedCounter; if d_countMirror != NULL
+ * (a device pointer, e.g. of mapped pinned host memory) the count is also stored there. */
 enum { VH_FUSED_GC = 1, VH_FUSED_STARVE = 2 };
 int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
-                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, vhStream_t stream);
+                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, uint32_t* d_countMirror,
+                       vhStream_t stream);
 
 /* ---- ray-cast launchers: DSC/CUDARayCastSDF.cpp:10-21 ----------------------- */
 /* renderCS(const HashData&, const RayCastData&, const DepthCameraData&, const RayCastParams&)

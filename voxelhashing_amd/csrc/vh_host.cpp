@@ -265,14 +265,16 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
     h_occupied = nullptr;
     m_occupiedEvent = nullptr;
     m_occupiedPending = false;
+    m_counterCleared = false;
     m_timer = new VhStageTimer(3);
     std::memset(&m_hashData, 0, sizeof(m_hashData));
     check(vh_hash_data_alloc(&m_hashData, &m_hashParams), "HashData::allocate");
-    checkHip(hipHostMalloc((void**)&h_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+    // mapped pinned word the fused integrate kernel mirrors the in-frustum block count into
+    checkHip(hipHostMalloc((void**)&h_occupied, sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc");
     *h_occupied = 0;
-    hipEvent_t ev;
-    checkHip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
-    m_occupiedEvent = ev;
+    void* dptr = nullptr;
+    checkHip(hipHostGetDevicePointer(&dptr, h_occupied, 0), "hipHostGetDevicePointer");
+    m_occupiedEvent = dptr; // device alias of h_occupied
     reset();
 }
 
@@ -281,7 +283,6 @@ void CUDASceneRepHashSDF::destroy()
     (void)hipStreamSynchronize((hipStream_t)m_stream);
     delete m_timer;
     m_timer = nullptr;
-    if (m_occupiedEvent) (void)hipEventDestroy((hipEvent_t)m_occupiedEvent);
     if (h_occupied) (void)hipHostFree(h_occupied);
     vh_hash_data_free(&m_hashData);
 }
@@ -293,9 +294,10 @@ void CUDASceneRepHashSDF::reset()
     const vh::mat4f id = vh::mat4f::identity();
     std::memcpy(m_hashParams.m_rigidTransform, id.m, sizeof(id.m));
     std::memcpy(m_hashParams.m_rigidTransformInverse, id.m, sizeof(id.m));
-    m_hashParams.m_numOccupiedBlocks = 0;
     pollOccupiedCount(true);
     *h_occupied = 0;
+    m_hashParams.m_numOccupiedBlocks = 0;
+    m_counterCleared = false;
     m_lockEpoch = 0;
     check(vh_reset(&m_hashData, &m_hashParams, m_stream), "resetCUDA");
 }
@@ -335,14 +337,13 @@ const vh::mat4f CUDASceneRepHashSDF::getLastRigidTransform() const
 void CUDASceneRepHashSDF::pollOccupiedCount(bool block)
 {
     if (!m_occupiedPending) return;
-    hipEvent_t ev = (hipEvent_t)m_occupiedEvent;
     if (block) {
-        checkHip(hipEventSynchronize(ev), "hipEventSynchronize");
-    } else if (hipEventQuery(ev) != hipSuccess) {
-        return;
+        checkHip(hipStreamSynchronize((hipStream_t)m_stream), "hipStreamSynchronize");
+        m_occupiedPending = false;
     }
-    m_hashParams.m_numOccupiedBlocks = *h_occupied;
-    m_occupiedPending = false;
+    // the fused integrate kernel stores the count of its frame into the mapped word; without blocking this is
+    // the count of the most recent frame whose kernel has run
+    m_hashParams.m_numOccupiedBlocks = *(volatile uint32_t*)h_occupied;
 }
 
 const HashParams& CUDASceneRepHashSDF::getHashParams()
@@ -353,8 +354,12 @@ const HashParams& CUDASceneRepHashSDF::getHashParams()
 
 unsigned int CUDASceneRepHashSDF::getNumOccupiedBlocks()
 {
-    pollOccupiedCount(true);
-    return m_hashParams.m_numOccupiedBlocks;
+    // exact: the device counter of the last compaction
+    uint32_t n = 0;
+    check(vh_memcpy_d2h(&n, m_hashData.d_hashCompactifiedCounter, sizeof(n), m_stream), "getNumOccupiedBlocks");
+    m_hashParams.m_numOccupiedBlocks = n;
+    m_occupiedPending = false;
+    return n;
 }
 
 // DSC/CUDASceneRepHashSDF.h:122-126
@@ -386,7 +391,8 @@ void CUDASceneRepHashSDF::integrate(const vh::mat4f& lastRigidTransform, const D
         }
         const bool timed = m_options.s_timingsDetailledEnabled;
         if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
-        check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), m_stream), "integrate (fused)");
+        check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), (uint32_t*)m_occupiedEvent, m_stream), "integrate (fused)");
+        m_occupiedPending = true;
         if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
     }
     m_numIntegratedFrames++;
@@ -409,6 +415,7 @@ void CUDASceneRepHashSDF::alloc(const DepthCameraData& cam, const DepthCameraPar
     } else {
         check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), m_stream), "allocCUDA");
     }
+    m_counterCleared = true; // k_alloc clears d_hashCompactifiedCounter
     if (timed) m_timer->stop(ST_ALLOC, (hipStream_t)m_stream);
 }
 
@@ -418,21 +425,16 @@ void CUDASceneRepHashSDF::compactifyHashEntries(const DepthCameraParams& cp)
     const bool timed = m_options.s_timingsDetailledEnabled;
     if (timed) m_timer->start(ST_COMPACTIFY, (hipStream_t)m_stream);
     const bool needHostCount = m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence;
+    // alloc() leaves the counter cleared; the stand-alone path (setLastRigidTransformAndCompactify) must clear it
+    const uint32_t flags = m_counterCleared ? VH_COMPACT_COUNTER_IS_ZERO : 0u;
+    m_counterCleared = false;
     if (needHostCount) {
-        pollOccupiedCount(true);
         uint32_t n = 0;
-        check(vh_compactify(&m_hashData, &m_hashParams, &cp, &n, m_stream), "compactifyHashAllInOneCUDA");
+        check(vh_compactify(&m_hashData, &m_hashParams, &cp, &n, flags, m_stream), "compactifyHashAllInOneCUDA");
         m_hashParams.m_numOccupiedBlocks = n;
+        m_occupiedPending = false;
     } else {
-        check(vh_compactify(&m_hashData, &m_hashParams, &cp, nullptr, m_stream), "compactifyHashAllInOneCUDA");
-        // non-blocking read-back for getHashParams(); skipped while the previous one is in flight
-        pollOccupiedCount(false);
-        if (!m_occupiedPending) {
-            checkHip(hipMemcpyAsync(h_occupied, m_hashData.d_hashCompactifiedCounter, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                    (hipStream_t)m_stream), "hipMemcpyAsync");
-            checkHip(hipEventRecord((hipEvent_t)m_occupiedEvent, (hipStream_t)m_stream), "hipEventRecord");
-            m_occupiedPending = true;
-        }
+        check(vh_compactify(&m_hashData, &m_hashParams, &cp, nullptr, flags, m_stream), "compactifyHashAllInOneCUDA");
     }
     if (timed) m_timer->stop(ST_COMPACTIFY, (hipStream_t)m_stream);
 }

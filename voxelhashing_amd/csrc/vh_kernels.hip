@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
     const uint32_t W = cp.m_imageWidth, H = cp.m_imageHeight;
     const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
     const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    // the compaction that follows needs its counter at zero: cleared here instead of by a separate memset
+    if (blockIdx.x == 0 && threadIdx.x == 0) hd.d_hashCompactifiedCounter[0] = 0;
     if (tile >= tilesX * tilesY) return; // wave-uniform
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
     const float vs = hp.m_virtualVoxelSize;
@@ -274,13 +276,15 @@ VHD float gc_key(Vox v) { return (v.weight() == 0u) ? pinf() : fabsf(v.sdf); }
 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_integrate(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
-                                                   VhDepthCameraParams cp, uint32_t flags, int32_t lockToken)
+                                                   VhDepthCameraParams cp, uint32_t flags, int32_t lockToken, uint32_t* countMirror)
 {
     __shared__ float sMin[4];
     __shared__ uint32_t sMax[4];
     __shared__ int sFreed;
 
     const uint32_t count = FUSED ? (uint32_t)hd.d_hashCompactifiedCounter[0] : hp.m_numOccupiedBlocks;
+    // host-visible copy of the block count (mapped pinned memory): replaces a per-frame device->host copy
+    if (FUSED && countMirror && blockIdx.x == 0 && threadIdx.x == 0) *countMirror = count;
     const uint32_t t = threadIdx.x;
     // voxel pair (2t, 2t+1): x = (2t)%8 (+1), y = (2t%64)/8, z = 2t/64  (delinearizeVoxelIndex, DSC/VoxelUtilHashSDF.h:313-318)
     const int lx = (int)((2u * t) & 7u), ly = (int)(((2u * t) & 63u) >> 3), lz = (int)((2u * t) >> 6);
@@ -986,11 +990,11 @@ int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraDa
 }
 
 int vh_compactify(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp,
-                  uint32_t* numOccupied, vhStream_t stream)
+                  uint32_t* numOccupied, uint32_t flags, vhStream_t stream)
 {
     if (!hd || !hp || !cp) return VH_ERR_BAD_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
-    VH_HIP(hipMemsetAsync(hd->d_hashCompactifiedCounter, 0, sizeof(int32_t), s));
+    if (!(flags & VH_COMPACT_COUNTER_IS_ZERO)) VH_HIP(hipMemsetAsync(hd->d_hashCompactifiedCounter, 0, sizeof(int32_t), s));
     const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
     k_compactify<<<cdiv(nWords, 256), 256, 0, s>>>(*hd, *hp, *cp);
     int err = vh_last_launch_error();
@@ -1007,17 +1011,17 @@ int vh_integrate(const VhHashData* hd, const VhHashParams* hp, const VhDepthCame
 {
     if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
     if (hp->m_numOccupiedBlocks == 0) return VH_OK; // DSC/CUDASceneRepHashSDF.cu:501
-    k_integrate<false><<<hp->m_numOccupiedBlocks, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, 0u, VH_LOCK_ENTRY);
+    k_integrate<false><<<hp->m_numOccupiedBlocks, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, 0u, VH_LOCK_ENTRY, nullptr);
     return vh_last_launch_error();
 }
 
 int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
-                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, vhStream_t stream)
+                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, uint32_t* d_countMirror, vhStream_t stream)
 {
     if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
     // persistent grid: the block count lives on the device, so no host read-back is needed
     const uint32_t grid = hp->m_numSDFBlocks < 2048u ? hp->m_numSDFBlocks : 2048u;
-    k_integrate<true><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken);
+    k_integrate<true><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken, d_countMirror);
     return vh_last_launch_error();
 }
 

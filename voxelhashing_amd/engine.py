@@ -361,7 +361,7 @@ class LauncherScene:
 
     def compactify(self, cp):
         n = C.c_uint32()
-        check(self.L.vh_compactify(C.byref(self.hd), C.byref(self.hp), C.byref(cp), C.byref(n), self.stream), "vh_compactify")
+        check(self.L.vh_compactify(C.byref(self.hd), C.byref(self.hp), C.byref(cp), C.byref(n), 0, self.stream), "vh_compactify")
         self.hp.m_numOccupiedBlocks = n.value
         return n.value
 
@@ -369,7 +369,7 @@ class LauncherScene:
         check(self.L.vh_integrate(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), self.stream), "vh_integrate")
 
     def integrate_fused(self, frame, cp, flags, lock_token):
-        check(self.L.vh_integrate_fused(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), flags, lock_token, self.stream),
+        check(self.L.vh_integrate_fused(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), flags, lock_token, None, self.stream),
               "vh_integrate_fused")
 
     def starve(self):

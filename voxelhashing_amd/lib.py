@@ -35,13 +35,13 @@ PROTOTYPES = {
     "vh_reset": (C.c_int, [P(T.HashData), P(T.HashParams), _VP]),
     "vh_reset_bucket_mutex": (C.c_int, [P(T.HashData), P(T.HashParams), _VP]),
     "vh_alloc": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), _VP, C.c_int32, _VP]),
-    "vh_compactify": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(C.c_uint32), _VP]),
+    "vh_compactify": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(C.c_uint32), C.c_uint32, _VP]),
     "vh_integrate": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), _VP]),
     "vh_starve": (C.c_int, [P(T.HashData), P(T.HashParams), _VP]),
     "vh_gc_identify": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _VP]),
     "vh_gc_free": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_int32, _VP]),
     "vh_bind_input_depth_color_textures": (C.c_int, [P(T.DepthCameraData)]),
-    "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP]),
+    "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP, _VP]),
     "vh_render": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP]),
     "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
