@@ -302,25 +302,37 @@ VHD int alloc_block(const VhHashData& hd, const VhHashParams& hp, I3 pos, int32_
     const uint32_t base = h * VH_HASH_BUCKET_SIZE;
 
     int firstEmpty = -1;
-#pragma unroll 1
-    for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
-        int4 q = load_quad(&hd.d_hash[base + j]);
-        if (quad_matches(q, pos)) return 0;
-        if (firstEmpty == -1 && q.w == VH_FREE_ENTRY) firstEmpty = (int)(base + j);
-    }
-
     const uint32_t idxLast = base + VH_HASH_BUCKET_SIZE - 1;
+    const uint32_t maxLoop = hp.m_hashMaxCollisionLinkedListSize;
     uint32_t i = idxLast;
     uint32_t maxIter = 0;
-    const uint32_t maxLoop = hp.m_hashMaxCollisionLinkedListSize;
+    if (!bucket_maybe_occupied(hd, h)) {
+        // empty bucket (no entry, hence no list hanging off its last slot): the first slot is the first free one.
+        // A stale bit can only hide an entry written earlier in THIS pass, whose writer still holds the bucket
+        // lock, so the lock attempt below fails exactly as it would after a full scan.
+        firstEmpty = (int)base;
+    } else {
+        // the ten slots and the list head in flight together
+        int4 qs[VH_HASH_BUCKET_SIZE];
+#pragma unroll
+        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) qs[j] = load_quad(&hd.d_hash[base + j]);
+        uint32_t off = hd.d_hash[idxLast].offset;
+#pragma unroll
+        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
+            if (quad_matches(qs[j], pos)) return 0;
+            if (firstEmpty == -1 && qs[j].w == VH_FREE_ENTRY) firstEmpty = (int)(base + j);
+        }
+        // collision list (the reference's first hop re-reads the last slot: no match, see above)
 #pragma unroll 1
-    while (maxIter < maxLoop) {
-        int4 q = load_quad(&hd.d_hash[i]);
-        if (quad_matches(q, pos)) return 0;
-        uint32_t off = hd.d_hash[i].offset;
-        if (off == 0) break;
-        i = (idxLast + off) % ne;
-        maxIter++;
+        while (maxIter < maxLoop) {
+            if (off == 0) break;
+            i = (idxLast + off) % ne;
+            maxIter++;
+            if (!(maxIter < maxLoop)) break;
+            int4 q = load_quad(&hd.d_hash[i]);
+            if (quad_matches(q, pos)) return 0;
+            off = hd.d_hash[i].offset;
+        }
     }
 
     if (firstEmpty != -1) {

@@ -77,7 +77,7 @@ VHD bool block_streamed_out(const VhHashParams& hp, I3 blk, const uint32_t* bitM
 }
 
 __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
-                                               VhDepthCameraParams cp, const uint32_t* bitMask, int32_t lockToken)
+                                               VhDepthCameraParams cp, const uint32_t* bitMask, int32_t lockToken, HashMod hm)
 {
     const uint32_t lane = lane_id();
     const uint32_t W = cp.m_imageWidth, H = cp.m_imageHeight;
@@ -126,6 +126,13 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
     uint32_t iter = 0;
     while (__any(active)) {
         bool want = active && block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask);
+        // Steady state: the block exists and sits in the first slot of its bucket.  Every lane checks that for
+        // its own block with ONE load (all lanes in flight together); only the rest -- new blocks and blocks
+        // further down a bucket -- goes through the serial allocBlock below.
+        if (want) {
+            const int4 q0 = load_quad(&hd.d_hash[hash_pos_fast(hm, id) * VH_HASH_BUCKET_SIZE]);
+            want = !quad_matches(q0, id);
+        }
         // wave-level de-duplication of the requested block ids
         uint64_t pending = __ballot(want);
         while (pending) {
@@ -177,11 +184,19 @@ __global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams 
         const uint32_t bucket = wordIdx * 32u + bit;
         bits &= bits - 1u;
         const VhHashEntry* e = &hd.d_hash[(uint64_t)bucket * VH_HASH_BUCKET_SIZE];
-#pragma unroll 1
+        // the whole bucket in flight at once (10 x 32 B)
+        int4 qs[VH_HASH_BUCKET_SIZE];
+        uint32_t offs[VH_HASH_BUCKET_SIZE];
+#pragma unroll
         for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
-            int4 q = make_int4(0, 0, 0, VH_FREE_ENTRY);
-            uint32_t off = 0;
-            if (has) { q = load_quad(&e[j]); off = e[j].offset; }
+            qs[j] = make_int4(0, 0, 0, VH_FREE_ENTRY);
+            offs[j] = 0;
+            if (has) { qs[j] = load_quad(&e[j]); offs[j] = e[j].offset; }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
+            const int4 q = qs[j];
+            const uint32_t off = offs[j];
             const bool keep = has && q.w != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(q.x, q.y, q.z));
             const uint64_t m = __ballot(keep);
             if (m) {
@@ -899,6 +914,9 @@ __global__ void k_debug_hash_ops(VhHashData hd, VhHashParams hp, const int32_t* 
         case VH_OP_NEW_PASS: token++; break;
         default: break;
         }
+        // ops are "passes" of one launch here: drop this CU's L1 so that plain loads of the next op see what the
+        // atomics of this one did at L2 (between real launches the hardware does that)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         results[i] = r;
     }
 }
@@ -985,7 +1003,8 @@ int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraDa
     if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
     const uint32_t tiles = cdiv(cp->m_imageWidth, 8) * cdiv(cp->m_imageHeight, 8);
     if (tiles == 0) return VH_OK;
-    k_alloc<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken);
+    if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
+    k_alloc<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken, make_hash_mod(hp->m_hashNumBuckets));
     return vh_last_launch_error();
 }
 
