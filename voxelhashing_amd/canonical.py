@@ -36,7 +36,7 @@ def snapshot(hash_table, sdf_blocks, heap, heap_counter, hp, with_voxels=True):
         ptrs=ptr,
         slots=idx[order],
         bucket_counts=bucket_counts,
-        heap_free=int(heap_counter) + 1,
+        heap_free=(int(heap_counter) + 1) & 0xFFFFFFFF,  # the counter is the top index: -1 (wrapped) when empty
         num_occupied=int(len(idx)),
     )
     if with_voxels:
@@ -53,7 +53,7 @@ def check_invariants(hash_table, heap, heap_counter, hp, sdf_blocks=None):
     allocated; every block is free or allocated; no duplicate positions; no
     LOCK_ENTRY left behind.  With sdf_blocks: every free block is all-zero."""
     n_blocks = hp.m_numSDFBlocks
-    n_free = int(heap_counter) + 1
+    n_free = (int(heap_counter) + 1) & 0xFFFFFFFF  # the counter is the top index: -1 (wrapped) when empty
     assert 0 <= n_free <= n_blocks, f"heap counter out of range: {heap_counter}"
     free_ids = heap[:n_free].astype(np.int64)
     assert free_ids.min(initial=0) >= 0 and free_ids.max(initial=0) < n_blocks
