@@ -46,7 +46,7 @@ def parse_args():
     p.add_argument("--offline", action="store_true", help="alloc until fixed point (blocking read-backs), as in parity runs")
     p.add_argument("--no-gc", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-frames", type=int, default=16, help="frames of the workload timed on the CPU oracle")
+    p.add_argument("--cpu-frames", type=int, default=40, help="frames of the workload timed on the CPU oracle")
     p.add_argument("--stages", action="store_true", help="also print per-stage device times to stderr")
     p.add_argument("--scene", default=None, help="override the scene (S1, S2)")
     return p.parse_args()

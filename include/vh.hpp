@@ -280,6 +280,7 @@ private:
     unsigned int* d_SDFBlockCounter;
     unsigned int* d_bitMask;
     void* m_copyStream; // hipStream_t of the worker thread
+    int m_device;       // HIP device the scene lives on (the worker thread binds to it)
 
     vh::vec3f m_voxelExtents;
     vh::vec3i m_gridDimensions;

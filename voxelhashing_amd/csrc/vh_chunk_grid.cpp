@@ -114,6 +114,7 @@ void CUDASceneRepChunkGrid::create(const vh::vec3f& voxelExtends, const vh::vec3
     checkHip(hipMalloc((void**)&d_SDFBlockInput, sizeof(vh::SDFBlock) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockCounter, sizeof(unsigned int)), "hipMalloc");
     checkHip(hipMalloc((void**)&d_bitMask, sizeof(unsigned int) * m_bitMask.size()), "hipMalloc");
+    checkHip(hipGetDevice(&m_device), "hipGetDevice"); // one instance is bound to one device
     hipStream_t cs;
     checkHip(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
     m_copyStream = cs;
@@ -140,9 +141,7 @@ void CUDASceneRepChunkGrid::destroy()
 
 void CUDASceneRepChunkGrid::workerLoop()
 {
-    if (m_sceneRepHashSDF) {
-        // same device as the scene (one instance is bound to one device)
-    }
+    (void)hipSetDevice(m_device); // the current device is per thread: bind the worker to the scene's GPU
     while (true) {
         streamOutToCPUPass1CPU(true);
         if (!m_sceneRepHashSDF->getOptions().s_offlineProcessing) {
