@@ -149,13 +149,19 @@ public:
     const RayCastParams& getRayCastParams() const { return m_params; } // :45
 
     void setTiming(bool on);
-    void getTimings(double out[3]); // ms: raycast, normals, frames
+    void getTimings(double out[3]); // ms: raycast (interval splat + march), normals, frames
+    // ray-interval splatting (DSC/CUDARayCastSDF.cpp:84-100, disabled in the reference fork): on by default here,
+    // as a conservative compute pass that leaves every output bit unchanged
+    void setIntervalSplatting(bool on) { m_useIntervals = on; }
 
 private:
     RayCastParams m_params;
     RayCastData m_data;
     vhStream_t m_stream;
     VhStageTimer* m_timer;
+    uint32_t* d_tileHeads;     // {min, max camera depth, block count, 0} per 8x8-pixel tile
+    VhTileBlock* d_tileBlocks; // VH_TILE_LIST_CAPACITY blocks per tile
+    bool m_useIntervals;
 };
 
 // ---------------------------------------------------------------------------

@@ -101,6 +101,21 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
  *                                                               DSC/CUDARayCastSDF.cu:59 */
 int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd,
               const VhDepthCameraParams* cp, const VhRayCastParams* rp, vhStream_t stream);
+/* Ray-interval splatting as a compute pass: resetRayIntervalSplatCUDA / rayIntervalSplatCUDA
+ * (DSC/CUDARayCastSDF.cu:88,169) + the D3D11 min/max rasterisation (DSC/DX11RayIntervalSplatting.cpp:150-220) that
+ * this fork leaves disabled.  Per 8x8-pixel tile (ceil(W/8)*ceil(H/8) of them, row-major):
+ *   d_tileHeads   4 words: {min, max} camera depth (float bits) of the allocated blocks the tile's rays can read,
+ *                 their number, 0;
+ *   d_tileBlocks  tileCapacity entries: those blocks (may be NULL: intervals only).  Lists longer than
+ *                 min(tileCapacity, VH_TILE_LIST_CAPACITY) are ignored by the ray caster (it probes the hash).
+ * Both are conservative (every allocated block, grown by the reach of a sample), so rendering with them gives
+ * bit-identical maps.  vh_render_intervals consumes and re-arms the heads; vh_ray_interval_clear arms them once. */
+int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height, vhStream_t stream);
+int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, const VhRayCastParams* rp,
+                          uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, vhStream_t stream);
+int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
+                        const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                        vhStream_t stream);
 /* computeNormals(float4* d_output, float4* d_input, width, height)  DSC/CameraUtil.cu:699 */
 int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream);
 
@@ -184,6 +199,8 @@ int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out);
 /* device time in ms of render() accumulated while timing is enabled: {raycast, normals, count} */
 int vh_raycast_get_timings(VhRayCast* r, double out[3]);
 int vh_raycast_set_timing(VhRayCast* r, int enabled);
+/* 1 (default): render() splats ray intervals first; 0: march the full depth range as this fork of the reference does */
+int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled);
 
 /* CUDASceneRepChunkGrid(sceneRep, voxelExtends, gridDimensions, minGridPos, initialChunkListSize,
  *                       streamingEnabled, streamOutParts)         DSC/CUDASceneRepChunkGrid.h:155 */

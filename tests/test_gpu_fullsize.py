@@ -54,6 +54,39 @@ def test_fused_equals_reference_launch_sequence_at_full_size(vh, cfg, scene_name
     assert np.allclose(np.linalg.norm(n[ok][:, :3].astype(np.float64), axis=1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("cfg,scene_name", [("cfg2", "S1"), ("cfg2", "S2"), ("cfg4", "S1")])
+def test_interval_splatting_does_not_change_a_bit(vh, cfg, scene_name):
+    """render() with the conservative ray intervals == the full-range march of the reference fork, for views from the
+    orbit, from far away, tilted so that blocks straddle the image border, and from inside the allocated band
+    (blocks behind and around the camera)"""
+    from voxelhashing_amd import engine as E
+    c = dict(synth.CONFIGS[cfg])
+    c.update(scene=scene_name, num_sdf_blocks=1 << 16)
+    hp, cp, rp = synth.config_params(c)
+    spheres, inside, radius = synth.scene(scene_name)
+    poses = [synth.orbit_pose(k, 200, radius) for k in range(6)]
+    frame = E.DepthFrame(cp)
+    scene, ray, _ = run_sequence(E, hp, cp, rp, T.make_scene_options(offline=True, gc=False), poses, frame, spheres, inside)
+    full = E.CUDARayCastSDF(rp)
+    full.setIntervalSplatting(False)
+    views = [poses[-1], synth.orbit_pose(40, 200, radius), synth.orbit_pose(3, 200, radius * 1.7)]
+    tilt = np.array(poses[2], dtype=np.float32).reshape(4, 4).copy()
+    a = 0.45
+    rot = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]], dtype=np.float32)
+    views.append(np.ascontiguousarray((tilt @ rot).astype(np.float32)).reshape(16))
+    near = np.array(poses[1], dtype=np.float32).reshape(4, 4).copy()
+    near[:3, 3] *= 0.35  # camera moved into / next to the surface band
+    views.append(np.ascontiguousarray(near).reshape(16))
+    hits = 0
+    for i, v in enumerate(views):
+        ray.render(scene.getHashData(), scene.getHashParams(), cp, v)
+        full.render(scene.getHashData(), scene.getHashParams(), cp, v)
+        ma, mb = ray.download(), full.download()
+        assert_maps_equal(ma, mb, f"view {i}: intervals vs full range")
+        hits += int((ma["depth"] != -np.inf).sum())
+    assert hits > 10000
+
+
 def test_online_mode_is_consistent_and_eventually_complete(vh):
     """online alloc (one pass per frame, losers retry next frame): after a few frames of a static view the block
     set equals the offline fixed point; the mirrored block count equals a blocking re-count"""

@@ -155,6 +155,12 @@ int vh_raycast_get_timings(VhRayCast* r, double out[3])
     if (!r || !out) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { r->impl.getTimings(out); });
 }
+int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    r->impl.setIntervalSplatting(enabled != 0);
+    return VH_OK;
+}
 int vh_raycast_set_timing(VhRayCast* r, int enabled)
 {
     if (!r) return VH_ERR_BAD_ARGUMENT;

@@ -549,6 +549,13 @@ CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
     checkHip(hipMalloc((void**)&m_data.d_depth4, sizeof(float) * 4 * n), "RayCastData::allocate");
     checkHip(hipMalloc((void**)&m_data.d_normals, sizeof(float) * 4 * n), "RayCastData::allocate");
     checkHip(hipMalloc((void**)&m_data.d_colors, sizeof(float) * 4 * n), "RayCastData::allocate");
+    d_tileHeads = nullptr;
+    d_tileBlocks = nullptr;
+    m_useIntervals = true;
+    const size_t tiles = (size_t)((params.m_width + 7) / 8) * ((params.m_height + 7) / 8);
+    checkHip(hipMalloc((void**)&d_tileHeads, sizeof(uint32_t) * 4 * (tiles ? tiles : 1)), "tile heads");
+    checkHip(hipMalloc((void**)&d_tileBlocks, sizeof(VhTileBlock) * VH_TILE_LIST_CAPACITY * (tiles ? tiles : 1)), "tile block lists");
+    check(vh_ray_interval_clear(d_tileHeads, params.m_width, params.m_height, m_stream), "vh_ray_interval_clear");
 }
 
 CUDARayCastSDF::~CUDARayCastSDF()
@@ -559,6 +566,8 @@ CUDARayCastSDF::~CUDARayCastSDF()
     if (m_data.d_depth4) (void)hipFree(m_data.d_depth4);
     if (m_data.d_normals) (void)hipFree(m_data.d_normals);
     if (m_data.d_colors) (void)hipFree(m_data.d_colors);
+    if (d_tileHeads) (void)hipFree(d_tileHeads);
+    if (d_tileBlocks) (void)hipFree(d_tileBlocks);
 }
 
 void CUDARayCastSDF::setTiming(bool on)
@@ -587,7 +596,12 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     std::memcpy(m_params.m_viewMatrixInverse, lastRigidTransform.m, sizeof(lastRigidTransform.m));
 
     if (m_timer) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream);
-    check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
+    if (m_useIntervals) {
+        check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "rayIntervalSplatCUDA");
+        check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "renderCS");
+    } else {
+        check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
+    }
     if (m_timer) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {
         if (m_timer) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);

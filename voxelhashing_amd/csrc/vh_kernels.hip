@@ -392,6 +392,97 @@ __global__ __launch_bounds__(256) void k_gc_free(VhHashData hd, VhHashParams hp,
 }
 
 // ---------------------------------------------------------------------------
+// ray-interval splatting as a compute pass (the reference rasterises block quads with D3D11 into min/max depth
+// textures, DSC/DX11RayIntervalSplatting.cpp:150-220 + rayIntervalSplatKernel DSC/CUDARayCastSDF.cu:101-167, and
+// this fork then ignores them: DSC/CUDARayCastSDF.cu:36-42).  Here every ALLOCATED block (not only the ones the
+// approximate frustum test keeps) is projected, one wave per block, and folded into the 8x8-pixel tiles it can
+// matter to:
+//   * head {min depth, max depth, count}: camera-depth range of those blocks (positive float bits: uint order =
+//     float order) and how many there are;
+//   * list: their {block position, voxel pointer}, up to `cap` per tile.
+// Both are conservative supersets, so rendering with them cannot change a result: a sample reads voxels within one
+// voxel of its position (two for the gradient), the box of a block is grown by more than that, and a perspective
+// projection maps a box in front of the camera into the hull of its projected corners.  A tile whose list is
+// complete therefore knows every block its rays can read: k_render resolves block -> pointer in LDS instead of
+// probing the hash table in HBM (and a block missing from the list is unallocated, as a failed probe would say).
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
+                                                        VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap)
+{
+    const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
+    const uint32_t wordIdx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t myBits = wordIdx < nWords ? hd.d_bucketBits[wordIdx] : 0u;
+    const int tilesX = (int)((rp.m_width + 7) / 8), tilesY = (int)((rp.m_height + 7) / 8);
+    const float vs = hp.m_virtualVoxelSize;
+    // voxel indices a sample at p can read along one axis: floor(p/vs) and floor(p/vs)+1 (+-1/2 more for the
+    // gradient's offset samples); block b holds indices 8b..8b+7  =>  p/vs in [8b-1, 8b+8) (+-1/2).  A quarter
+    // voxel on top covers every rounding on the way (|p/vs| < 2^16 where the quotient is resolved to 2^-8).
+    const float growLo = (rp.m_useGradients ? 1.75f : 1.25f) * vs, growHi = (rp.m_useGradients ? 0.75f : 0.25f) * vs;
+
+    uint64_t pending = __ballot(myBits != 0u);
+    while (pending) { // wave-uniform loops: one bucket, then one block, at a time, the 64 lanes share its tiles
+        const int src = __ffsll((long long)pending) - 1;
+        pending &= pending - 1ull;
+        uint32_t w = (uint32_t)__shfl((int)myBits, src);
+        const uint32_t wi = (uint32_t)__shfl((int)wordIdx, src);
+        while (w) {
+            const uint32_t bucket = wi * 32u + (uint32_t)(__ffs((int)w) - 1);
+            w &= w - 1u;
+            int4 q = make_int4(0, 0, 0, VH_FREE_ENTRY);
+            if (lane < VH_HASH_BUCKET_SIZE) q = load_quad(&hd.d_hash[(uint64_t)bucket * VH_HASH_BUCKET_SIZE + lane]);
+            uint64_t alloc = __ballot(q.w != VH_FREE_ENTRY);
+            while (alloc) {
+                const int sl = __ffsll((long long)alloc) - 1;
+                alloc &= alloc - 1ull;
+                const int bx = __shfl(q.x, sl), by = __shfl(q.y, sl), bz = __shfl(q.z, sl), ptr = __shfl(q.w, sl);
+                const float lox = (float)(bx * VH_SDF_BLOCK_SIZE) * vs - growLo, hix = (float)(bx * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+                const float loy = (float)(by * VH_SDF_BLOCK_SIZE) * vs - growLo, hiy = (float)(by * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+                const float loz = (float)(bz * VH_SDF_BLOCK_SIZE) * vs - growLo, hiz = (float)(bz * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+                float zmin = pinf(), zmax = minf(), xmin = pinf(), xmax = minf(), ymin = pinf(), ymax = minf();
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const F3 pc = mat_mul_p(rp.m_viewMatrix, mk3((c & 1) ? hix : lox, (c & 2) ? hiy : loy, (c & 4) ? hiz : loz));
+                    zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
+                    const float iz = 1.0f / fmaxf(pc.z, 1e-6f);
+                    const float sx = pc.x * cp.fx * iz + cp.mx, sy = pc.y * cp.fy * iz + cp.my;
+                    xmin = fminf(xmin, sx); xmax = fmaxf(xmax, sx);
+                    ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy);
+                }
+                if (!(zmax > 0.0f)) continue; // entirely behind the camera: no sample (depth > 0) lies in it
+                int tx0 = 0, ty0 = 0, tx1 = tilesX - 1, ty1 = tilesY - 1;
+                if (zmin > 0.05f) { // box in front of the camera; otherwise it may project anywhere: every tile
+                    const float slop = 1.0f + 1e-3f * fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax)));
+                    // clamp in float first: the float -> int conversion of a huge coordinate is not defined
+                    tx0 = (int)fminf(fmaxf(floorf((xmin - slop) * 0.125f), 0.0f), (float)tilesX);
+                    ty0 = (int)fminf(fmaxf(floorf((ymin - slop) * 0.125f), 0.0f), (float)tilesY);
+                    tx1 = (int)fminf(fmaxf(floorf((xmax + slop) * 0.125f), -1.0f), (float)(tilesX - 1));
+                    ty1 = (int)fminf(fmaxf(floorf((ymax + slop) * 0.125f), -1.0f), (float)(tilesY - 1));
+                }
+                if (tx1 < tx0 || ty1 < ty0) continue; // off screen
+                const float zs = 1e-3f * fabsf(zmax) + 0.5f * vs;
+                const uint32_t lo = __float_as_uint(fmaxf(zmin - zs, 0.0f)), hi = __float_as_uint(fmaxf(zmax + zs, 0.0f));
+                const uint32_t nx = (uint32_t)(tx1 - tx0 + 1), n = nx * (uint32_t)(ty1 - ty0 + 1);
+                for (uint32_t i = lane; i < n; i += kWave) {
+                    const uint32_t t = (uint32_t)(ty0 + (int)(i / nx)) * (uint32_t)tilesX + (uint32_t)(tx0 + (int)(i % nx));
+                    atomicMin(&heads[t].x, lo);
+                    atomicMax(&heads[t].y, hi);
+                    const uint32_t slot = atomicAdd(&heads[t].z, 1u);
+                    if (slot < cap) lists[(size_t)t * cap + slot] = make_int4(bx, by, bz, ptr);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_interval_clear(uint4* heads, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) heads[i] = make_uint4(0x7f800000u, 0u, 0u, 0u); // empty: {+inf, 0, no blocks}
+}
+
+// ---------------------------------------------------------------------------
 // ray caster (renderKernel DSC/CUDARayCastSDF.cu:18-57,
 // traverseCoarseGridSimpleSampleAll DSC/RayCastSDFUtil.h:198-262)
 //
@@ -446,6 +537,50 @@ VHD int cached_lookup(const VhHashData& hd, const VhHashParams& hp, HashMod hm, 
     return p;
 }
 
+constexpr int kPtrUnknown = -3; // "first tap not resolved yet" (never a block pointer, VH_FREE_ENTRY or VH_LOCK_ENTRY)
+constexpr uint32_t kTileTabSlots = 2 * VH_TILE_LIST_CAPACITY; // LDS table per wave: load factor <= 1/2
+
+// block -> voxel pointer through the hash table in HBM
+struct HashLookup {
+    static constexpr bool kResolvesFirstTap = false;
+    const VhHashData& hd;
+    const VhHashParams& hp;
+    HashMod hm;
+    BlockCache bc;
+    VHD int find(int bx, int by, int bz) { return cached_lookup(hd, hp, hm, bc, bx, by, bz); }
+    // may the sample whose first tap lies in this block be valid?  (occupancy bit of the bucket: one cached dword)
+    VHD bool first_tap(int bx, int by, int bz, int& p0)
+    {
+        p0 = kPtrUnknown;
+        return bucket_maybe_occupied(hd, hash_pos_fast(hm, mki3(bx, by, bz)));
+    }
+};
+
+// block -> voxel pointer through the tile's own table in LDS (open addressing, built from the tile's block list);
+// a block that is not in it is not allocated (k_interval_splat lists every block the tile's rays can read)
+struct TileLookup {
+    static constexpr bool kResolvesFirstTap = true;
+    const int4* tab;
+    VHD static uint32_t slot_of(int bx, int by, int bz)
+    {
+        return ((uint32_t)bx * 73856093u ^ (uint32_t)by * 19349669u ^ (uint32_t)bz * 83492791u) & (kTileTabSlots - 1u);
+    }
+    VHD int find(int bx, int by, int bz) const
+    {
+        uint32_t h = slot_of(bx, by, bz);
+        for (;;) {
+            const int4 e = tab[h];
+            if (e.w == VH_FREE_ENTRY || (e.x == bx && e.y == by && e.z == bz)) return e.w;
+            h = (h + 1u) & (kTileTabSlots - 1u);
+        }
+    }
+    VHD bool first_tap(int bx, int by, int bz, int& p0) const
+    {
+        p0 = find(bx, by, bz);
+        return p0 != VH_FREE_ENTRY;
+    }
+};
+
 VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 {
     return *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]);
@@ -459,18 +594,17 @@ VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 // see trilinear_partial below).  The colour is accumulated only on request:
 // the reference computes it for every sample but reads it only from the last
 // bisection sample (RayCastSDFUtil.h:231,241).
-template <bool COLOR>
-VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, HashMod hm, BlockCache& bc, int x0, int y0, int z0, int x1, int y1, int z1,
+template <bool COLOR, class LK>
+VHD bool trilinear(const VhHashData& hd, float vs, LK& lk, int p0in, int x0, int y0, int z0, int x1, int y1, int z1,
                    F3 pos, float rvs, float& dist, uint32_t& colorOut)
 {
-    const float vs = hp.m_virtualVoxelSize;
     const int bxa = vvp_to_block1(x0), bya = vvp_to_block1(y0), bza = vvp_to_block1(z0);
     const int bxb = vvp_to_block1(x1), byb = vvp_to_block1(y1), bzb = vvp_to_block1(z1);
     // bit a of `straddle`: the tap pair along axis a lies in two different blocks
     const uint32_t straddle = (bxb != bxa ? 1u : 0u) | (byb != bya ? 2u : 0u) | (bzb != bza ? 4u : 0u);
 
     // block pointer per tap combo (bit0 = x1, bit1 = y1, bit2 = z1); one probe per DISTINCT block
-    int p0 = cached_lookup(hd, hp, hm, bc, bxa, bya, bza);
+    int p0 = (LK::kResolvesFirstTap && p0in != kPtrUnknown) ? p0in : lk.find(bxa, bya, bza);
     if (p0 == VH_FREE_ENTRY) return false; // the first tap reads the zero voxel (weight 0)
     int p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
     if (straddle) {
@@ -481,7 +615,7 @@ VHD bool trilinear(const VhHashData& hd, const VhHashParams& hp, HashMod hm, Blo
 #pragma unroll 1
         while (need) {
             const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
-            const int p = cached_lookup(hd, hp, hm, bc, (k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
+            const int p = lk.find((k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
             if (p == VH_FREE_ENTRY) return false;
             const uint32_t km = k & straddle;
             if (((1u) & straddle) == km) p1 = p;
@@ -614,141 +748,210 @@ VHD void tap_coords(const RayQ& rq, float t, int& x0, int& y0, int& z0, int& x1,
     }
 }
 
-template <bool GRADIENTS>
-__global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd,
-                                                VhDepthCameraParams cp, VhRayCastParams rp, HashMod hm)
-{
-    const uint32_t lane = lane_id();
-    const uint32_t W = rp.m_width, H = rp.m_height;
-    const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
-    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    if (tile >= tilesX * tilesY) return;
-    const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
-    if (x >= W || y >= H) return;
-    const size_t pix = (size_t)y * W + x;
+struct RayOut {
+    float depth;
+    float4 depth4, normal, color;
+};
 
-    const float mi = minf();
-    float outDepth = mi;
-    float4 outDepth4 = make_float4(mi, mi, mi, mi), outNormal = outDepth4, outColor = outDepth4;
+// traverseCoarseGridSimpleSampleAll, DSC/RayCastSDFUtil.h:198-262, for the ray of pixel (x, y), restricted to the
+// tile's conservative depth interval [tileZmin, tileZmax].  Written as march-until-sign-change / bisect / resume so
+// that the lanes of a wave run their bisections together instead of interleaving them with other lanes' marching;
+// each ray's own sequence of samples is the reference's.
+template <bool GRADIENTS, class LK>
+VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
+                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayOut& out
 #ifdef VH_RENDER_STATS
-    const long long statT0 = clock64();
-    const long long statR0 = wall_clock64();
-    float statTri = 0.0f, statIter = 0.0f;
+                   , float& statTri, float& statIter
 #endif
-
+)
+{
+    const float mi = minf();
     const F3 camDir = normalize3(depth_to_skeleton(cp, x, y, proj_to_cam_z(cp, 1.0f)));
     const F3 worldCamPos = mat_mul_p(rp.m_viewMatrixInverse, mk3(0.0f, 0.0f, 0.0f));
     const F3 worldDir = normalize3(mat_mul_d(rp.m_viewMatrixInverse, camDir));
 
     const float minInterval = rp.m_minDepth, maxInterval = rp.m_maxDepth;
     const bool run = !(minInterval == 0.0f || minInterval == mi) && !(maxInterval == 0.0f || maxInterval == mi);
-    if (run) {
-        const float depthToRayLength = 1.0f / camDir.z;
-        const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
-        const float inc = rp.m_rayIncrement;
-        RayQ rq;
-        rq.cam = worldCamPos; rq.dir = worldDir;
-        rq.vs = hp.m_virtualVoxelSize;
-        rq.rvs = 1.0f / rq.vs; // IEEE reciprocal for div_exact
-        rq.halfVoxel = rq.vs / 2.0f;
-        rq.camq = mk3(worldCamPos.x * rq.rvs, worldCamPos.y * rq.rvs, worldCamPos.z * rq.rvs);
-        rq.dirq = mk3(worldDir.x * rq.rvs, worldDir.y * rq.rvs, worldDir.z * rq.rvs);
-        {
-            // Q bounds |pos/voxel| for every sample of this ray (march and bisection parameters are <= rayEnd)
-            const float Q = 1.0f + (fabsf(rq.camq.x) + fabsf(rq.camq.y) + fabsf(rq.camq.z)) +
-                            fabsf(rayEnd) * (fabsf(rq.dirq.x) + fabsf(rq.dirq.y) + fabsf(rq.dirq.z));
-            const float margin = Q * (32.0f / 16777216.0f);
-            rq.certLim = (Q < 65536.0f) ? 0.5f - margin : -1.0f; // NaN/inf Q compare false: exact path
-        }
-        BlockCache bc;
-        cache_init(bc);
+    if (!run) return;
+    const float depthToRayLength = 1.0f / camDir.z;
+    const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
+    const float inc = rp.m_rayIncrement;
+    RayQ rq;
+    rq.cam = worldCamPos; rq.dir = worldDir;
+    rq.vs = hp.m_virtualVoxelSize;
+    rq.rvs = 1.0f / rq.vs; // IEEE reciprocal for div_exact
+    rq.halfVoxel = rq.vs / 2.0f;
+    rq.camq = mk3(worldCamPos.x * rq.rvs, worldCamPos.y * rq.rvs, worldCamPos.z * rq.rvs);
+    rq.dirq = mk3(worldDir.x * rq.rvs, worldDir.y * rq.rvs, worldDir.z * rq.rvs);
+    {
+        // Q bounds |pos/voxel| for every sample of this ray (march and bisection parameters are <= rayEnd)
+        const float Q = 1.0f + (fabsf(rq.camq.x) + fabsf(rq.camq.y) + fabsf(rq.camq.z)) +
+                        fabsf(rayEnd) * (fabsf(rq.dirq.x) + fabsf(rq.dirq.y) + fabsf(rq.dirq.z));
+        const float margin = Q * (32.0f / 16777216.0f);
+        rq.certLim = (Q < 65536.0f) ? 0.5f - margin : -1.0f; // NaN/inf Q compare false: exact path
+    }
 
-        // traverseCoarseGridSimpleSampleAll, DSC/RayCastSDFUtil.h:198-262.  Written as march-until-sign-change /
-        // bisect / resume so that the lanes of a wave run their bisections together instead of interleaving
-        // them with other lanes' marching; each ray's own sequence of samples is the reference's.
-        float rcur = depthToRayLength * fmaxf(rp.m_minDepth, minInterval); // rayCurrent
-        float lastSdf = 0.0f, lastAlpha = 0.0f;
-        int lastValid = 0; // flags live in VGPRs: on this kernel the scalar unit (one per CU) is the scarce resource
+    float rcur = depthToRayLength * fmaxf(rp.m_minDepth, minInterval); // rayCurrent
+    float lastSdf = 0.0f, lastAlpha = 0.0f;
+    int lastValid = 0; // flags live in VGPRs: on this kernel the scalar unit (one per CU) is the scarce resource
+
+    // Interval of the tile in ray-parameter units.  Samples before it have their first tap in no allocated block
+    // (they are invalid: lastValid = 0), samples after it likewise, so nothing can be hit there.  rcur still
+    // advances by the same sequence of additions, one VALU op per skipped sample.
+    const float tSkip = depthToRayLength * tileZmin;
+    const float tStop = fminf(rayEnd, depthToRayLength * tileZmax);
+#pragma unroll 1
+    while (rcur < tSkip && rcur < rayEnd) rcur += inc;
 
 #pragma unroll 1
-        for (;;) {
-            // ---- A: skip samples whose first tap has no block (they are invalid: weight 0 at the first tap).
-            // Tight loop: the lanes of a wave leave it at their next sample with a first tap, or at the end.
-            int x0, y0, z0, x1, y1, z1;
-            int skipped = 0;
+    for (;;) {
+        // ---- A: skip samples whose first tap has no block (they are invalid: weight 0 at the first tap).
+        // Tight loop: the lanes of a wave leave it at their next sample with a first tap, or at the end.
+        int x0, y0, z0, x1, y1, z1, p0 = kPtrUnknown;
+        int skipped = 0;
 #pragma unroll 1
-            while (rcur < rayEnd) {
+        while (rcur < tStop) {
 #ifdef VH_RENDER_STATS
-                statIter += 1.0f;
+            statIter += 1.0f;
 #endif
-                tap_coords(rq, rcur, x0, y0, z0, x1, y1, z1);
-                // x >> 3 = vvp_to_block1(x): the arithmetic shift floors
-                if (bucket_maybe_occupied(hd, hash_pos_fast(hm, mki3(x0 >> 3, y0 >> 3, z0 >> 3)))) break;
-                skipped = 1;
-                rcur += inc;
-            }
-            if (!(rcur < rayEnd)) break; // ray left the depth range
-            lastValid = skipped ? 0 : lastValid;
-
-            // ---- B: full sample at rcur
-#ifdef VH_RENDER_STATS
-            statTri += 1.0f;
-#endif
-            float dist = 0.0f;
-            uint32_t colorUnused = 0u;
-            const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
-            const bool ok = trilinear<false>(hd, hp, hm, bc, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
-
-            if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) {
-                // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur]
-                float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
-                uint32_t color2 = 0u;
-                bool success = true;
-#pragma unroll 1
-                for (int i = 0; i < 3; i++) {
-#ifdef VH_RENDER_STATS
-                    statIter += 1.0f; statTri += 1.0f;
-#endif
-                    c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
-                    int cx0, cy0, cz0, cx1, cy1, cz1;
-                    tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
-                    const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
-                    float cDist = 0.0f;
-                    if (!trilinear<true>(hd, hp, hm, bc, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
-                    if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
-                    else { b = c; bDist = cDist; }
-                }
-                if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
-                    const float alpha = c;
-                    const float depth = alpha / depthToRayLength;
-                    outDepth = depth;
-                    const F3 sk = depth_to_skeleton(cp, x, y, depth);
-                    outDepth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
-                    outColor = make_float4((float)(color2 & 0xffu) / 255.f, (float)((color2 >> 8) & 0xffu) / 255.f,
-                                           (float)((color2 >> 16) & 0xffu) / 255.f, 1.0f);
-                    if (GRADIENTS) {
-                        const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
-                        const F3 g = gradient_for_point(hd, hp, bc, iso);
-                        const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
-                        outNormal = make_float4(n.x, n.y, n.z, 1.0f);
-                    }
-                    break;
-                }
-                // no accepted hit: the march sample becomes the last sample and the march goes on (:248-252)
-            }
-            lastSdf = ok ? dist : lastSdf;
-            lastAlpha = ok ? rcur : lastAlpha;
-            lastValid = ok ? 1 : 0;
+            tap_coords(rq, rcur, x0, y0, z0, x1, y1, z1);
+            // x >> 3 = vvp_to_block1(x): the arithmetic shift floors
+            if (lk.first_tap(x0 >> 3, y0 >> 3, z0 >> 3, p0)) break;
+            skipped = 1;
             rcur += inc;
         }
-    }
+        if (!(rcur < tStop)) break; // ray left the depth range (or the range in which blocks exist)
+        lastValid = skipped ? 0 : lastValid;
+
+        // ---- B: full sample at rcur
 #ifdef VH_RENDER_STATS
-    outNormal = make_float4((float)(clock64() - statT0), statTri, statIter, (float)(wall_clock64() - statR0));
+        statTri += 1.0f;
 #endif
-    rd.d_depth[pix] = outDepth;
-    reinterpret_cast<float4*>(rd.d_depth4)[pix] = outDepth4;
-    reinterpret_cast<float4*>(rd.d_normals)[pix] = outNormal;
-    reinterpret_cast<float4*>(rd.d_colors)[pix] = outColor;
+        float dist = 0.0f;
+        uint32_t colorUnused = 0u;
+        const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
+        const bool ok = trilinear<false>(hd, rq.vs, lk, p0, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
+
+        if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) {
+            // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur]
+            float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
+            uint32_t color2 = 0u;
+            bool success = true;
+#pragma unroll 1
+            for (int i = 0; i < 3; i++) {
+#ifdef VH_RENDER_STATS
+                statIter += 1.0f; statTri += 1.0f;
+#endif
+                c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
+                int cx0, cy0, cz0, cx1, cy1, cz1;
+                tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
+                const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
+                float cDist = 0.0f;
+                if (!trilinear<true>(hd, rq.vs, lk, kPtrUnknown, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
+                if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
+                else { b = c; bDist = cDist; }
+            }
+            if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
+                const float alpha = c;
+                const float depth = alpha / depthToRayLength;
+                out.depth = depth;
+                const F3 sk = depth_to_skeleton(cp, x, y, depth);
+                out.depth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
+                out.color = make_float4((float)(color2 & 0xffu) / 255.f, (float)((color2 >> 8) & 0xffu) / 255.f,
+                                        (float)((color2 >> 16) & 0xffu) / 255.f, 1.0f);
+                if (GRADIENTS) {
+                    const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
+                    BlockCache unused;
+                    cache_init(unused);
+                    const F3 g = gradient_for_point(hd, hp, unused, iso);
+                    const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
+                    out.normal = make_float4(n.x, n.y, n.z, 1.0f);
+                }
+                break;
+            }
+            // no accepted hit: the march sample becomes the last sample and the march goes on (:248-252)
+        }
+        lastSdf = ok ? dist : lastSdf;
+        lastAlpha = ok ? rcur : lastAlpha;
+        lastValid = ok ? 1 : 0;
+        rcur += inc;
+    }
+}
+
+// One wave per 8x8-pixel tile.  With tile heads/lists from k_interval_splat the wave first builds its block table in
+// LDS; without them (or when the tile's list overflowed) it probes the hash table as the reference does.
+template <bool GRADIENTS>
+__global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd,
+                                                VhDepthCameraParams cp, VhRayCastParams rp, HashMod hm,
+                                                uint4* heads, const int4* lists, uint32_t cap)
+{
+    __shared__ int4 tileTab[256 / kWave][kTileTabSlots];
+    const uint32_t lane = lane_id();
+    const uint32_t W = rp.m_width, H = rp.m_height;
+    const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
+    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (tile >= tilesX * tilesY) return;
+    // conservative camera-depth interval / block list of this tile; consumed and re-armed here so that no separate
+    // clear pass is needed
+    float tileZmin = 0.0f, tileZmax = pinf();
+    bool useTable = false;
+    int4* tab = tileTab[threadIdx.x / kWave];
+    if (heads) {
+        const uint4 hd4 = heads[tile];
+        tileZmin = __uint_as_float(hd4.x);
+        tileZmax = __uint_as_float(hd4.y);
+        if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
+        const uint32_t n = hd4.z;
+        useTable = lists != nullptr && n <= cap && n <= (uint32_t)VH_TILE_LIST_CAPACITY;
+        if (useTable && n > 0u) {
+            for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i] = make_int4(0, 0, 0, VH_FREE_ENTRY);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n) {
+                const int4 e = lists[(size_t)tile * cap + lane];
+                uint32_t h = TileLookup::slot_of(e.x, e.y, e.z);
+                // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
+                while (atomicCAS(&tab[h].w, VH_FREE_ENTRY, e.w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
+                tab[h].x = e.x; tab[h].y = e.y; tab[h].z = e.z;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x >= W || y >= H) return;
+    const size_t pix = (size_t)y * W + x;
+
+    const float mi = minf();
+    RayOut out;
+    out.depth = mi;
+    out.depth4 = out.normal = out.color = make_float4(mi, mi, mi, mi);
+#ifdef VH_RENDER_STATS
+    const long long statT0 = clock64();
+    const long long statR0 = wall_clock64();
+    float statTri = 0.0f, statIter = 0.0f;
+#define VH_STAT_ARGS , statTri, statIter
+#else
+#define VH_STAT_ARGS
+#endif
+    if (!(tileZmin <= tileZmax)) {
+        // no allocated block can be read by this tile's rays: every sample is invalid, nothing is hit
+    } else if (useTable) {
+        TileLookup lk{ tab };
+        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out VH_STAT_ARGS);
+    } else {
+        HashLookup lk{ hd, hp, hm, {} };
+        cache_init(lk.bc);
+        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out VH_STAT_ARGS);
+    }
+#undef VH_STAT_ARGS
+#ifdef VH_RENDER_STATS
+    out.normal = make_float4((float)(clock64() - statT0), statTri, statIter, (float)(wall_clock64() - statR0));
+#endif
+    rd.d_depth[pix] = out.depth;
+    reinterpret_cast<float4*>(rd.d_depth4)[pix] = out.depth4;
+    reinterpret_cast<float4*>(rd.d_normals)[pix] = out.normal;
+    reinterpret_cast<float4*>(rd.d_colors)[pix] = out.color;
 }
 
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
@@ -1082,8 +1285,45 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
     if (tiles == 0) return VH_OK;
     if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
     const HashMod hm = make_hash_mod(hp->m_hashNumBuckets);
-    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm);
-    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm);
+    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, nullptr, nullptr, 0u);
+    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, nullptr, nullptr, 0u);
+    return vh_last_launch_error();
+}
+
+int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
+                        const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                        vhStream_t stream)
+{
+    if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
+    if (tiles == 0) return VH_OK;
+    if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
+    const HashMod hm = make_hash_mod(hp->m_hashNumBuckets);
+    uint4* h = reinterpret_cast<uint4*>(d_tileHeads);
+    const int4* l = reinterpret_cast<const int4*>(d_tileBlocks);
+    const uint32_t cap = d_tileBlocks ? tileCapacity : 0u;
+    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, h, l, cap);
+    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, h, l, cap);
+    return vh_last_launch_error();
+}
+
+int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_tileHeads) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t tiles = cdiv(width, 8) * cdiv(height, 8);
+    if (tiles == 0) return VH_OK;
+    k_interval_clear<<<cdiv(tiles, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<uint4*>(d_tileHeads), tiles);
+    return vh_last_launch_error();
+}
+
+int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, const VhRayCastParams* rp,
+                          uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, vhStream_t stream)
+{
+    if (!hd || !hp || !cp || !rp || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
+    if (rp->m_width == 0 || rp->m_height == 0) return VH_OK;
+    const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
+    k_interval_splat<<<cdiv(nWords, 256), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
+                                                                       reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u);
     return vh_last_launch_error();
 }
 

@@ -215,6 +215,9 @@ class CUDARayCastSDF:
     def setTiming(self, on):
         check(self.L.vh_raycast_set_timing(self.handle, 1 if on else 0), "setTiming")
 
+    def setIntervalSplatting(self, on):
+        check(self.L.vh_raycast_set_interval_splatting(self.handle, 1 if on else 0), "setIntervalSplatting")
+
     def getTimings(self):
         out = (C.c_double * 3)()
         check(self.L.vh_raycast_get_timings(self.handle, out), "getTimings")

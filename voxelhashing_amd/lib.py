@@ -43,6 +43,9 @@ PROTOTYPES = {
     "vh_bind_input_depth_color_textures": (C.c_int, [P(T.DepthCameraData)]),
     "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP, _VP]),
     "vh_render": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP]),
+    "vh_ray_interval_clear": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_ray_interval_splat": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP]),
+    "vh_render_intervals": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP]),
     "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
     "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
@@ -71,6 +74,7 @@ PROTOTYPES = {
     "vh_raycast_get_params": (C.c_int, [_VP, P(T.RayCastParams)]),
     "vh_raycast_get_timings": (C.c_int, [_VP, P(C.c_double)]),
     "vh_raycast_set_timing": (C.c_int, [_VP, C.c_int]),
+    "vh_raycast_set_interval_splatting": (C.c_int, [_VP, C.c_int]),
     "vh_chunk_grid_create": (C.c_int, [_VP, _F16, P(C.c_int32), P(C.c_int32), C.c_uint32, C.c_int, C.c_uint32, P(_VP)]),
     "vh_chunk_grid_destroy": (None, [_VP]),
     "vh_chunk_grid_stream_out_to_cpu_pass0_gpu": (C.c_int, [_VP, _F16, C.c_float, C.c_int, C.c_int]),
