@@ -126,7 +126,7 @@ class GpuWorkload:
             self.frames.append(fr)
         self.scene = E.CUDASceneRepHashSDF(self.hp, self.opt)
         self.ray = E.CUDARayCastSDF(self.rp)
-        self.ray.setTiming(True)
+        self.ray.setTiming(True, march_only=True)  # live HIP events around k_render, every frame
         self.hd = self.scene.getHashData()
         torch.cuda.synchronize()
 
@@ -141,6 +141,7 @@ class GpuWorkload:
     def stage_timers(self, on):
         self.opt.s_timingsDetailledEnabled = 1 if on else 0
         self.scene.setOptions(self.opt)
+        self.ray.setTiming(True, march_only=not on)
 
     def timings(self):
         s = self.scene.getTimings()
@@ -232,7 +233,7 @@ def main():
     torch.cuda.synchronize()
     s1 = wl.timings()
     wl.stage_timers(False)
-    stage_us = {k[:-3]: 1e3 * (s1[k] - s0[k]) / max(n_stage, 1) for k in ("alloc_ms", "compactify_ms", "integrate_ms", "raycast_ms", "normals_ms")}
+    stage_us = {k[:-3]: 1e3 * (s1[k] - s0[k]) / max(n_stage, 1) for k in ("alloc_ms", "compactify_ms", "integrate_ms", "splat_ms", "raycast_ms", "normals_ms")}
 
     pre = {}
 

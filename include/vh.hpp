@@ -148,8 +148,8 @@ public:
     const RayCastData& getRayCastData() { return m_data; }        // :42
     const RayCastParams& getRayCastParams() const { return m_params; } // :45
 
-    void setTiming(bool on);
-    void getTimings(double out[3]); // ms: raycast (interval splat + march), normals, frames
+    void setTiming(bool on, bool marchOnly = false); // marchOnly: events around the march kernel only
+    void getTimings(double out[4]); // ms: raycast (the march kernel), normals, frames, interval splat
     // ray-interval splatting (DSC/CUDARayCastSDF.cpp:84-100, disabled in the reference fork): on by default here,
     // as a conservative compute pass that leaves every output bit unchanged
     void setIntervalSplatting(bool on) { m_useIntervals = on; }
@@ -159,6 +159,7 @@ private:
     RayCastData m_data;
     vhStream_t m_stream;
     VhStageTimer* m_timer;
+    bool m_timeMarchOnly;
     uint32_t* d_tileHeads;     // {min, max camera depth, block count, 0} per 8x8-pixel tile
     VhTileBlock* d_tileBlocks; // VH_TILE_LIST_CAPACITY blocks per tile
     bool m_useIntervals;

@@ -196,9 +196,10 @@ int vh_raycast_render(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp
 /* getRayCastData() :42 / getRayCastParams() :45 */
 int vh_raycast_get_data(VhRayCast* r, VhRayCastData* out);
 int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out);
-/* device time in ms of render() accumulated while timing is enabled: {raycast, normals, count} */
-int vh_raycast_get_timings(VhRayCast* r, double out[3]);
-int vh_raycast_set_timing(VhRayCast* r, int enabled);
+/* device time in ms of render() accumulated while timing is enabled: {raycast (march kernel), normals, count,
+ * interval splat} */
+int vh_raycast_get_timings(VhRayCast* r, double out[4]);
+int vh_raycast_set_timing(VhRayCast* r, int enabled); /* 0 off, 1 every stage, 2 the march kernel only */
 /* 1 (default): render() splats ray intervals first; 0: march the full depth range as this fork of the reference does */
 int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled);
 

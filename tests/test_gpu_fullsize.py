@@ -69,6 +69,12 @@ def test_interval_splatting_does_not_change_a_bit(vh, cfg, scene_name):
     scene, ray, _ = run_sequence(E, hp, cp, rp, T.make_scene_options(offline=True, gc=False), poses, frame, spheres, inside)
     full = E.CUDARayCastSDF(rp)
     full.setIntervalSplatting(False)
+    import ctypes as C
+    from voxelhashing_amd import lib
+    L = lib.load()
+    n_tiles = ((cp.m_imageWidth + 7) // 8) * ((cp.m_imageHeight + 7) // 8)
+    heads, small_lists = lib.DeviceBuffer(n_tiles * 16), lib.DeviceBuffer(n_tiles * 3 * 16)
+    lib.check(L.vh_ray_interval_clear(heads.ptr, cp.m_imageWidth, cp.m_imageHeight, None))
     views = [poses[-1], synth.orbit_pose(40, 200, radius), synth.orbit_pose(3, 200, radius * 1.7)]
     tilt = np.array(poses[2], dtype=np.float32).reshape(4, 4).copy()
     a = 0.45
@@ -84,6 +90,17 @@ def test_interval_splatting_does_not_change_a_bit(vh, cfg, scene_name):
         ma, mb = ray.download(), full.download()
         assert_maps_equal(ma, mb, f"view {i}: intervals vs full range")
         hits += int((ma["depth"] != -np.inf).sum())
+        # launcher level: lists that overflow (capacity 3: misses fall back to the hash table) and no lists at all
+        hd, hpp, rpp, rd = scene.getHashData(), scene.getHashParams(), full.getRayCastParams(), full.getRayCastData()
+        for cap, blocks in ((3, small_lists), (0, None)):
+            lib.check(L.vh_ray_interval_splat(C.byref(hd), C.byref(hpp), C.byref(cp), C.byref(rpp), heads.ptr,
+                                              blocks.ptr if blocks else None, cap, None))
+            lib.check(L.vh_render_intervals(C.byref(hd), C.byref(hpp), C.byref(rd), C.byref(cp), C.byref(rpp), heads.ptr,
+                                            blocks.ptr if blocks else None, cap, None))
+            mc = full.download()
+            for k in ("depth", "depth4", "colors"):  # normals are computeNormals' output of the class-level call
+                assert np.array_equal(mc[k].view(np.uint32), mb[k].view(np.uint32)), f"view {i} capacity {cap}: {k}"
+        assert np.all(heads.download(np.uint32).reshape(-1, 4) == np.array([0x7f800000, 0, 0, 0], dtype=np.uint32)), "heads re-armed"
     assert hits > 10000
 
 

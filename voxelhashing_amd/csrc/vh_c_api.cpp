@@ -150,7 +150,7 @@ int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out)
     *out = r->impl.getRayCastParams();
     return VH_OK;
 }
-int vh_raycast_get_timings(VhRayCast* r, double out[3])
+int vh_raycast_get_timings(VhRayCast* r, double out[4])
 {
     if (!r || !out) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { r->impl.getTimings(out); });
@@ -164,7 +164,7 @@ int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled)
 int vh_raycast_set_timing(VhRayCast* r, int enabled)
 {
     if (!r) return VH_ERR_BAD_ARGUMENT;
-    return guarded([&] { r->impl.setTiming(enabled != 0); });
+    return guarded([&] { r->impl.setTiming(enabled != 0, enabled == 2); });
 }
 
 // ---- CUDASceneRepChunkGrid ----------------------------------------------------

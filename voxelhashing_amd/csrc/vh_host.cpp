@@ -226,7 +226,7 @@ vec3f mat4f::transformPoint(const vec3f& v) const
 // CUDASceneRepHashSDF
 // ---------------------------------------------------------------------------
 
-enum { ST_ALLOC = 0, ST_COMPACTIFY = 1, ST_INTEGRATE = 2, ST_RAYCAST = 0, ST_NORMALS = 1 };
+enum { ST_ALLOC = 0, ST_COMPACTIFY = 1, ST_INTEGRATE = 2, ST_RAYCAST = 0, ST_NORMALS = 1, ST_SPLAT = 2 };
 
 VhSceneOptions CUDASceneRepHashSDF::defaultOptions()
 {
@@ -540,7 +540,7 @@ void CUDASceneRepHashSDF::debugHash(unsigned int report[4])
 // ---------------------------------------------------------------------------
 
 CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
-    : m_params(params), m_stream(stream), m_timer(nullptr)
+    : m_params(params), m_stream(stream), m_timer(nullptr), m_timeMarchOnly(false)
 {
     std::memset(&m_data, 0, sizeof(m_data));
     const size_t n = (size_t)params.m_width * params.m_height;
@@ -570,20 +570,22 @@ CUDARayCastSDF::~CUDARayCastSDF()
     if (d_tileBlocks) (void)hipFree(d_tileBlocks);
 }
 
-void CUDARayCastSDF::setTiming(bool on)
+void CUDARayCastSDF::setTiming(bool on, bool marchOnly)
 {
-    if (on && !m_timer) m_timer = new VhStageTimer(2);
+    m_timeMarchOnly = marchOnly;
+    if (on && !m_timer) m_timer = new VhStageTimer(3);
     if (!on && m_timer) { delete m_timer; m_timer = nullptr; }
 }
 
-void CUDARayCastSDF::getTimings(double out[3])
+void CUDARayCastSDF::getTimings(double out[4])
 {
-    out[0] = out[1] = out[2] = 0.0;
+    out[0] = out[1] = out[2] = out[3] = 0.0;
     if (!m_timer) return;
     m_timer->resolve((hipStream_t)m_stream);
     out[0] = m_timer->totalMs[ST_RAYCAST];
     out[1] = m_timer->totalMs[ST_NORMALS];
     out[2] = (double)m_timer->count[ST_RAYCAST];
+    out[3] = m_timer->totalMs[ST_SPLAT];
 }
 
 // DSC/CUDARayCastSDF.cpp:38-72 with rayIntervalSplatting :84-100 (view matrices only)
@@ -595,17 +597,21 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     std::memcpy(m_params.m_viewMatrix, view.m, sizeof(view.m));
     std::memcpy(m_params.m_viewMatrixInverse, lastRigidTransform.m, sizeof(lastRigidTransform.m));
 
-    if (m_timer) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream);
     if (m_useIntervals) {
+        if (m_timer && !m_timeMarchOnly) m_timer->start(ST_SPLAT, (hipStream_t)m_stream);
         check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "rayIntervalSplatCUDA");
+        if (m_timer && !m_timeMarchOnly) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
+    }
+    if (m_timer) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
+    if (m_useIntervals) {
         check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "renderCS");
     } else {
         check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
     }
     if (m_timer) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {
-        if (m_timer) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
+        if (m_timer && !m_timeMarchOnly) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
         check(vh_compute_normals(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, m_stream), "computeNormals");
-        if (m_timer) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
+        if (m_timer && !m_timeMarchOnly) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
     }
 }

@@ -407,13 +407,18 @@ __global__ __launch_bounds__(256) void k_gc_free(VhHashData hd, VhHashParams hp,
 // probing the hash table in HBM (and a block missing from the list is unallocated, as a failed probe would say).
 // ---------------------------------------------------------------------------
 
+constexpr uint32_t kSplatWordsPerWave = 8;
+
 __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
                                                         VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap)
 {
+    // kSplatWordsPerWave occupancy words per wave: a block costs a wave a few dependent round trips (slots, then the
+    // list slot of each tile), so the fewer blocks a wave meets, the shorter the kernel; the tile loop uses all lanes
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
-    const uint32_t wordIdx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = lane_id();
-    const uint32_t myBits = wordIdx < nWords ? hd.d_bucketBits[wordIdx] : 0u;
+    const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const uint32_t wordIdx = wave * kSplatWordsPerWave + lane;
+    const uint32_t myBits = (lane < kSplatWordsPerWave && wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
     const int tilesX = (int)((rp.m_width + 7) / 8), tilesY = (int)((rp.m_height + 7) / 8);
     const float vs = hp.m_virtualVoxelSize;
     // voxel indices a sample at p can read along one axis: floor(p/vs) and floor(p/vs)+1 (+-1/2 more for the
@@ -464,12 +469,23 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
                 const float zs = 1e-3f * fabsf(zmax) + 0.5f * vs;
                 const uint32_t lo = __float_as_uint(fmaxf(zmin - zs, 0.0f)), hi = __float_as_uint(fmaxf(zmax + zs, 0.0f));
                 const uint32_t nx = (uint32_t)(tx1 - tx0 + 1), n = nx * (uint32_t)(ty1 - ty0 + 1);
-                for (uint32_t i = lane; i < n; i += kWave) {
-                    const uint32_t t = (uint32_t)(ty0 + (int)(i / nx)) * (uint32_t)tilesX + (uint32_t)(tx0 + (int)(i % nx));
-                    atomicMin(&heads[t].x, lo);
-                    atomicMax(&heads[t].y, hi);
-                    const uint32_t slot = atomicAdd(&heads[t].z, 1u);
-                    if (slot < cap) lists[(size_t)t * cap + slot] = make_int4(bx, by, bz, ptr);
+                for (uint32_t base = 0; base < n; base += 4u * kWave) {
+                    // four tiles per lane in flight: the list slots come back from L2 together
+                    uint32_t t[4], slot[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        const uint32_t i = base + j * kWave + lane;
+                        t[j] = (uint32_t)(ty0 + (int)(i / nx)) * (uint32_t)tilesX + (uint32_t)(tx0 + (int)(i % nx));
+                        slot[j] = 0xffffffffu;
+                        if (i < n) {
+                            slot[j] = atomicAdd(&heads[t[j]].z, 1u);
+                            atomicMin(&heads[t[j]].x, lo);
+                            atomicMax(&heads[t[j]].y, hi);
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++)
+                        if (slot[j] < cap) lists[(size_t)t[j] * cap + slot[j]] = make_int4(bx, by, bz, ptr);
                 }
             }
         }
@@ -556,11 +572,20 @@ struct HashLookup {
     }
 };
 
-// block -> voxel pointer through the tile's own table in LDS (open addressing, built from the tile's block list);
-// a block that is not in it is not allocated (k_interval_splat lists every block the tile's rays can read)
+__device__ __noinline__ int lookup_ptr_slow(const VhHashData hd, const VhHashParams hp, int bx, int by, int bz)
+{
+    return lookup_ptr(hd, hp, mki3(bx, by, bz));
+}
+
+// block -> voxel pointer through the tile's own table in LDS (open addressing, built from the tile's block list).
+// k_interval_splat lists every block the tile's rays can read, so a block that is not in a COMPLETE table is not
+// allocated; when the list overflowed, the table holds a part of it and a miss falls back to the hash table.
 struct TileLookup {
     static constexpr bool kResolvesFirstTap = true;
     const int4* tab;
+    bool complete;
+    const VhHashData& hd;
+    const VhHashParams& hp;
     VHD static uint32_t slot_of(int bx, int by, int bz)
     {
         return ((uint32_t)bx * 73856093u ^ (uint32_t)by * 19349669u ^ (uint32_t)bz * 83492791u) & (kTileTabSlots - 1u);
@@ -568,11 +593,14 @@ struct TileLookup {
     VHD int find(int bx, int by, int bz) const
     {
         uint32_t h = slot_of(bx, by, bz);
+        int4 e;
         for (;;) {
-            const int4 e = tab[h];
-            if (e.w == VH_FREE_ENTRY || (e.x == bx && e.y == by && e.z == bz)) return e.w;
+            e = tab[h]; // one 16-byte LDS read; all four words decide (no short circuit: it would split the read)
+            if ((int)(e.w == VH_FREE_ENTRY) | ((int)(e.x == bx) & (int)(e.y == by) & (int)(e.z == bz))) break;
             h = (h + 1u) & (kTileTabSlots - 1u);
         }
+        if (e.w == VH_FREE_ENTRY && !complete) return lookup_ptr(hd, hp, mki3(bx, by, bz));
+        return e.w;
     }
     VHD bool first_tap(int bx, int by, int bz, int& p0) const
     {
@@ -581,9 +609,14 @@ struct TileLookup {
     }
 };
 
+// One 8-byte load per voxel.  As an (indivisible) relaxed atomic: an ordinary load is split by the compiler into its
+// two words, and the sdf word is then fetched only after the weight test -- a second trip to memory per sample.
 VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 {
-    return *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]);
+    const unsigned long long v = __hip_atomic_load(
+        reinterpret_cast<const unsigned long long*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
 // trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116, for tap
@@ -748,9 +781,12 @@ VHD void tap_coords(const RayQ& rq, float t, int& x0, int& y0, int& z0, int& x1,
     }
 }
 
-struct RayOut {
-    float depth;
-    float4 depth4, normal, color;
+struct RayHit {
+    float alpha;    // ray parameter of the accepted intersection; NaN-free flag in `hit`
+    uint32_t color; // packed colour of the last bisection sample
+    bool hit;
+    float depthToRayLength;
+    F3 normal;      // GRADIENTS only (camera space)
 };
 
 // traverseCoarseGridSimpleSampleAll, DSC/RayCastSDFUtil.h:198-262, for the ray of pixel (x, y), restricted to the
@@ -759,7 +795,7 @@ struct RayOut {
 // each ray's own sequence of samples is the reference's.
 template <bool GRADIENTS, class LK>
 VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
-                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayOut& out
+                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayHit& out
 #ifdef VH_RENDER_STATS
                    , float& statTri, float& statIter
 #endif
@@ -774,6 +810,7 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
     const bool run = !(minInterval == 0.0f || minInterval == mi) && !(maxInterval == 0.0f || maxInterval == mi);
     if (!run) return;
     const float depthToRayLength = 1.0f / camDir.z;
+    out.depthToRayLength = depthToRayLength;
     const float rayEnd = depthToRayLength * fminf(rp.m_maxDepth, maxInterval);
     const float inc = rp.m_rayIncrement;
     RayQ rq;
@@ -805,85 +842,152 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
 
 #pragma unroll 1
     for (;;) {
-        // ---- A: skip samples whose first tap has no block (they are invalid: weight 0 at the first tap).
-        // Tight loop: the lanes of a wave leave it at their next sample with a first tap, or at the end.
-        int x0, y0, z0, x1, y1, z1, p0 = kPtrUnknown;
-        int skipped = 0;
+        // ---- march until a sign change (or the end of the range).  The lanes of a wave leave this loop together:
+        // whichever lane finds its sign change first waits here, so that the wave runs ONE bisection phase for all
+        // of them instead of one per march step.  Each ray's own sequence of samples is the reference's.
+        bool candidate = false;
+        float dist = 0.0f;
 #pragma unroll 1
-        while (rcur < tStop) {
+        for (;;) {
+            // ---- A: skip samples whose first tap has no block (they are invalid: weight 0 at the first tap)
+            int x0, y0, z0, x1, y1, z1, p0 = kPtrUnknown;
+            int skipped = 0;
+#pragma unroll 1
+            while (rcur < tStop) {
 #ifdef VH_RENDER_STATS
-            statIter += 1.0f;
+                statIter += 1024.0f / (float)__popcll(__ballot(1));
 #endif
-            tap_coords(rq, rcur, x0, y0, z0, x1, y1, z1);
-            // x >> 3 = vvp_to_block1(x): the arithmetic shift floors
-            if (lk.first_tap(x0 >> 3, y0 >> 3, z0 >> 3, p0)) break;
-            skipped = 1;
+                tap_coords(rq, rcur, x0, y0, z0, x1, y1, z1);
+                // x >> 3 = vvp_to_block1(x): the arithmetic shift floors
+                if (lk.first_tap(x0 >> 3, y0 >> 3, z0 >> 3, p0)) break;
+                skipped = 1;
+                rcur += inc;
+            }
+            if (!(rcur < tStop)) break; // ray left the depth range (or the range in which blocks exist)
+            lastValid = skipped ? 0 : lastValid;
+
+            // ---- B: full sample at rcur
+#ifdef VH_RENDER_STATS
+            statTri += 1.0f;
+            statIter += 1.0f / (float)__popcll(__ballot(1));
+#endif
+            uint32_t colorUnused = 0u;
+            const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
+            const bool ok = trilinear<false>(hd, rq.vs, lk, p0, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
+            if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) { candidate = true; break; }
+            lastSdf = ok ? dist : lastSdf;
+            lastAlpha = ok ? rcur : lastAlpha;
+            lastValid = ok ? 1 : 0;
             rcur += inc;
         }
-        if (!(rcur < tStop)) break; // ray left the depth range (or the range in which blocks exist)
-        lastValid = skipped ? 0 : lastValid;
+        if (!candidate) break;
 
-        // ---- B: full sample at rcur
-#ifdef VH_RENDER_STATS
-        statTri += 1.0f;
-#endif
-        float dist = 0.0f;
-        uint32_t colorUnused = 0u;
-        const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
-        const bool ok = trilinear<false>(hd, rq.vs, lk, p0, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
-
-        if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) {
-            // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur]
-            float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
-            uint32_t color2 = 0u;
-            bool success = true;
+        // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur]
+        float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
+        uint32_t color2 = 0u;
+        bool success = true;
 #pragma unroll 1
-            for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 3; i++) {
 #ifdef VH_RENDER_STATS
-                statIter += 1.0f; statTri += 1.0f;
+            statTri += 1.0f;
+            statIter += 1.0f / (float)__popcll(__ballot(1));
 #endif
-                c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
-                int cx0, cy0, cz0, cx1, cy1, cz1;
-                tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
-                const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
-                float cDist = 0.0f;
-                if (!trilinear<true>(hd, rq.vs, lk, kPtrUnknown, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
-                if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
-                else { b = c; bDist = cDist; }
-            }
-            if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
-                const float alpha = c;
-                const float depth = alpha / depthToRayLength;
-                out.depth = depth;
-                const F3 sk = depth_to_skeleton(cp, x, y, depth);
-                out.depth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
-                out.color = make_float4((float)(color2 & 0xffu) / 255.f, (float)((color2 >> 8) & 0xffu) / 255.f,
-                                        (float)((color2 >> 16) & 0xffu) / 255.f, 1.0f);
-                if (GRADIENTS) {
-                    const F3 iso = mk3(worldCamPos.x + alpha * worldDir.x, worldCamPos.y + alpha * worldDir.y, worldCamPos.z + alpha * worldDir.z);
-                    BlockCache unused;
-                    cache_init(unused);
-                    const F3 g = gradient_for_point(hd, hp, unused, iso);
-                    const F3 n = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
-                    out.normal = make_float4(n.x, n.y, n.z, 1.0f);
-                }
-                break;
-            }
-            // no accepted hit: the march sample becomes the last sample and the march goes on (:248-252)
+            c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
+            int cx0, cy0, cz0, cx1, cy1, cz1;
+            tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
+            const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
+            float cDist = 0.0f;
+            if (!trilinear<true>(hd, rq.vs, lk, kPtrUnknown, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
+            if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
+            else { b = c; bDist = cDist; }
         }
-        lastSdf = ok ? dist : lastSdf;
-        lastAlpha = ok ? rcur : lastAlpha;
-        lastValid = ok ? 1 : 0;
+        if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
+            out.hit = true;
+            out.alpha = c;
+            out.color = color2;
+            if (GRADIENTS) {
+                const F3 iso = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
+                BlockCache unused;
+                cache_init(unused);
+                const F3 g = gradient_for_point(hd, hp, unused, iso);
+                out.normal = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
+            }
+            break;
+        }
+        // no accepted hit: the (valid) march sample becomes the last sample and the march goes on (:248-252)
+        lastSdf = dist;
+        lastAlpha = rcur;
+        lastValid = 1;
         rcur += inc;
     }
 }
 
-// One wave per 8x8-pixel tile.  With tile heads/lists from k_interval_splat the wave first builds its block table in
-// LDS; without them (or when the tile's list overflowed) it probes the hash table as the reference does.
+// the maps of one pixel (renderKernel DSC/CUDARayCastSDF.cu:18-57; outputs of traverseCoarseGridSimpleSampleAll :236-247)
+VHD void store_ray(const VhRayCastData& rd, const VhDepthCameraParams& cp, size_t pix, uint32_t x, uint32_t y, const RayHit& r, bool gradients)
+{
+    const float mi = minf();
+    float depth = mi;
+    float4 depth4 = make_float4(mi, mi, mi, mi), normal = depth4, color = depth4;
+    if (r.hit) {
+        depth = r.alpha / r.depthToRayLength;
+        const F3 sk = depth_to_skeleton(cp, x, y, depth);
+        depth4 = make_float4(sk.x, sk.y, sk.z, 1.0f);
+        color = make_float4((float)(r.color & 0xffu) / 255.f, (float)((r.color >> 8) & 0xffu) / 255.f, (float)((r.color >> 16) & 0xffu) / 255.f, 1.0f);
+        if (gradients) normal = make_float4(r.normal.x, r.normal.y, r.normal.z, 1.0f);
+    }
+    rd.d_depth[pix] = depth;
+    reinterpret_cast<float4*>(rd.d_depth4)[pix] = depth4;
+    reinterpret_cast<float4*>(rd.d_normals)[pix] = normal;
+    reinterpret_cast<float4*>(rd.d_colors)[pix] = color;
+}
+
+#ifdef VH_RENDER_STATS
+#define VH_STAT_DECL const long long statT0 = clock64(); const long long statR0 = wall_clock64(); float statTri = 0.0f, statIter = 0.0f;
+#define VH_STAT_ARGS , statTri, statIter
+#define VH_STAT_STORE                                                                                                                   \
+    {                                                                                                                                   \
+        const uint32_t hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);              \
+        reinterpret_cast<float4*>(rd.d_normals)[pix] = make_float4((float)(clock64() - statT0), statTri, statIter, (float)(wall_clock64() - statR0)); \
+        reinterpret_cast<float4*>(rd.d_colors)[pix] = make_float4((float)(uint32_t)(statR0 & 0xffffffll), (float)((hwid >> 8) & 0xfu),  \
+            (float)((hwid >> 13) & 0x7u) + 8.0f * (float)((hwid >> 12) & 1u), (float)(xcc & 0xfu) * 4.0f + (float)((hwid >> 4) & 3u));   \
+    }
+#else
+#define VH_STAT_DECL
+#define VH_STAT_ARGS
+#define VH_STAT_STORE
+#endif
+
+// One wave per 8x8-pixel tile, block pointers from the hash table: the reference fork's ray caster (no intervals).
 template <bool GRADIENTS>
-__global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd,
-                                                VhDepthCameraParams cp, VhRayCastParams rp, HashMod hm,
-                                                uint4* heads, const int4* lists, uint32_t cap)
+__global__ __launch_bounds__(256) void k_render_hash(VhHashData hd, VhHashParams hp, VhRayCastData rd,
+                                                     VhDepthCameraParams cp, VhRayCastParams rp, HashMod hm)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t W = rp.m_width, H = rp.m_height;
+    const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
+    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (tile >= tilesX * tilesY) return;
+    const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x >= W || y >= H) return;
+    const size_t pix = (size_t)y * W + x;
+    VH_STAT_DECL
+    RayHit out;
+    out.hit = false;
+    HashLookup lk{ hd, hp, hm, {} };
+    cache_init(lk.bc);
+    march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, 0.0f, pinf(), out VH_STAT_ARGS);
+    store_ray(rd, cp, pix, x, y, out, GRADIENTS);
+    VH_STAT_STORE
+}
+
+// One wave per 8x8-pixel tile with the tile's head and block list from k_interval_splat: the wave builds its
+// block table in LDS and marches inside the tile's depth interval.  5 waves per SIMD keep all tiles of a 640x480
+// frame resident at once (4800 waves <= 5 x 4 x 256): the march is a latency chain, and a second round of waves
+// costs as much as the first.
+template <bool GRADIENTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
+              uint4* heads, const int4* lists, uint32_t cap)
 {
     __shared__ int4 tileTab[256 / kWave][kTileTabSlots];
     const uint32_t lane = lane_id();
@@ -891,68 +995,42 @@ __global__ __launch_bounds__(256) void k_render(VhHashData hd, VhHashParams hp, 
     const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
     const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     if (tile >= tilesX * tilesY) return;
-    // conservative camera-depth interval / block list of this tile; consumed and re-armed here so that no separate
-    // clear pass is needed
-    float tileZmin = 0.0f, tileZmax = pinf();
-    bool useTable = false;
     int4* tab = tileTab[threadIdx.x / kWave];
-    if (heads) {
-        const uint4 hd4 = heads[tile];
-        tileZmin = __uint_as_float(hd4.x);
-        tileZmax = __uint_as_float(hd4.y);
-        if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
-        const uint32_t n = hd4.z;
-        useTable = lists != nullptr && n <= cap && n <= (uint32_t)VH_TILE_LIST_CAPACITY;
-        if (useTable && n > 0u) {
-            for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i] = make_int4(0, 0, 0, VH_FREE_ENTRY);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < n) {
-                const int4 e = lists[(size_t)tile * cap + lane];
-                uint32_t h = TileLookup::slot_of(e.x, e.y, e.z);
-                // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
-                while (atomicCAS(&tab[h].w, VH_FREE_ENTRY, e.w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
-                tab[h].x = e.x; tab[h].y = e.y; tab[h].z = e.z;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+    // consume the head and re-arm it, so that no separate clear pass is needed
+    const uint4 head = heads[tile];
+    const float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y);
+    if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
+    const uint32_t listed = min(head.z, min(cap, (uint32_t)VH_TILE_LIST_CAPACITY));
+    const bool complete = listed == head.z;
+    for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i] = make_int4(0, 0, 0, VH_FREE_ENTRY);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < listed) {
+        const int4 e = lists[(size_t)tile * cap + lane];
+        uint32_t h = TileLookup::slot_of(e.x, e.y, e.z);
+        // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
+        while (atomicCAS(&tab[h].w, VH_FREE_ENTRY, e.w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
+        tab[h].x = e.x; tab[h].y = e.y; tab[h].z = e.z;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
     if (x >= W || y >= H) return;
     const size_t pix = (size_t)y * W + x;
-
-    const float mi = minf();
-    RayOut out;
-    out.depth = mi;
-    out.depth4 = out.normal = out.color = make_float4(mi, mi, mi, mi);
-#ifdef VH_RENDER_STATS
-    const long long statT0 = clock64();
-    const long long statR0 = wall_clock64();
-    float statTri = 0.0f, statIter = 0.0f;
-#define VH_STAT_ARGS , statTri, statIter
-#else
-#define VH_STAT_ARGS
-#endif
-    if (!(tileZmin <= tileZmax)) {
-        // no allocated block can be read by this tile's rays: every sample is invalid, nothing is hit
-    } else if (useTable) {
-        TileLookup lk{ tab };
-        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out VH_STAT_ARGS);
-    } else {
-        HashLookup lk{ hd, hp, hm, {} };
-        cache_init(lk.bc);
+    VH_STAT_DECL
+    RayHit out;
+    out.hit = false;
+    if (tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
+        TileLookup lk{ tab, complete, hd, hp };
         march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out VH_STAT_ARGS);
     }
-#undef VH_STAT_ARGS
-#ifdef VH_RENDER_STATS
-    out.normal = make_float4((float)(clock64() - statT0), statTri, statIter, (float)(wall_clock64() - statR0));
-#endif
-    rd.d_depth[pix] = out.depth;
-    reinterpret_cast<float4*>(rd.d_depth4)[pix] = out.depth4;
-    reinterpret_cast<float4*>(rd.d_normals)[pix] = out.normal;
-    reinterpret_cast<float4*>(rd.d_colors)[pix] = out.color;
+    store_ray(rd, cp, pix, x, y, out, GRADIENTS);
+    VH_STAT_STORE
 }
+#undef VH_STAT_DECL
+#undef VH_STAT_ARGS
+#undef VH_STAT_STORE
 
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
 __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height)
@@ -1285,8 +1363,8 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
     if (tiles == 0) return VH_OK;
     if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
     const HashMod hm = make_hash_mod(hp->m_hashNumBuckets);
-    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, nullptr, nullptr, 0u);
-    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, nullptr, nullptr, 0u);
+    if (rp->m_useGradients) k_render_hash<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm);
+    else k_render_hash<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm);
     return vh_last_launch_error();
 }
 
@@ -1297,13 +1375,11 @@ int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRa
     if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
     if (tiles == 0) return VH_OK;
-    if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
-    const HashMod hm = make_hash_mod(hp->m_hashNumBuckets);
     uint4* h = reinterpret_cast<uint4*>(d_tileHeads);
     const int4* l = reinterpret_cast<const int4*>(d_tileBlocks);
     const uint32_t cap = d_tileBlocks ? tileCapacity : 0u;
-    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, h, l, cap);
-    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, hm, h, l, cap);
+    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap);
+    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap);
     return vh_last_launch_error();
 }
 
@@ -1322,7 +1398,7 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
     if (!hd || !hp || !cp || !rp || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     if (rp->m_width == 0 || rp->m_height == 0) return VH_OK;
     const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
-    k_interval_splat<<<cdiv(nWords, 256), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
+    k_interval_splat<<<cdiv(cdiv(nWords, kSplatWordsPerWave), 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
                                                                        reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u);
     return vh_last_launch_error();
 }

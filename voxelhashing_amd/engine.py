@@ -212,16 +212,16 @@ class CUDARayCastSDF:
         check(self.L.vh_raycast_get_params(self.handle, C.byref(rp)), "getRayCastParams")
         return rp
 
-    def setTiming(self, on):
-        check(self.L.vh_raycast_set_timing(self.handle, 1 if on else 0), "setTiming")
+    def setTiming(self, on, march_only=False):
+        check(self.L.vh_raycast_set_timing(self.handle, (2 if march_only else 1) if on else 0), "setTiming")
 
     def setIntervalSplatting(self, on):
         check(self.L.vh_raycast_set_interval_splatting(self.handle, 1 if on else 0), "setIntervalSplatting")
 
     def getTimings(self):
-        out = (C.c_double * 3)()
+        out = (C.c_double * 4)()
         check(self.L.vh_raycast_get_timings(self.handle, out), "getTimings")
-        return dict(raycast_ms=out[0], normals_ms=out[1], frames=int(out[2]))
+        return dict(raycast_ms=out[0], normals_ms=out[1], frames=int(out[2]), splat_ms=out[3])
 
     def download(self):
         rd = self.getRayCastData()
