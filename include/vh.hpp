@@ -148,7 +148,8 @@ public:
     const RayCastData& getRayCastData() { return m_data; }        // :42
     const RayCastParams& getRayCastParams() const { return m_params; } // :45
 
-    void setTiming(bool on, bool marchOnly = false); // marchOnly: events around the march kernel only
+    // marchOnly: events around the march kernel only; stride n: only every n-th render() is timed
+    void setTiming(bool on, bool marchOnly = false, unsigned int stride = 1);
     void getTimings(double out[4]); // ms: raycast (the march kernel), normals, frames, interval splat
     // ray-interval splatting (DSC/CUDARayCastSDF.cpp:84-100, disabled in the reference fork): on by default here,
     // as a conservative compute pass that leaves every output bit unchanged
@@ -160,6 +161,7 @@ private:
     vhStream_t m_stream;
     VhStageTimer* m_timer;
     bool m_timeMarchOnly;
+    unsigned int m_timeStride, m_renderCalls;
     uint32_t* d_tileHeads;     // {min, max camera depth, block count, 0} per 8x8-pixel tile
     VhTileBlock* d_tileBlocks; // VH_TILE_LIST_CAPACITY blocks per tile
     bool m_useIntervals;

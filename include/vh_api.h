@@ -200,6 +200,8 @@ int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out);
  * interval splat} */
 int vh_raycast_get_timings(VhRayCast* r, double out[4]);
 int vh_raycast_set_timing(VhRayCast* r, int enabled); /* 0 off, 1 every stage, 2 the march kernel only */
+/* same, timing only every stride-th render() (an event record idles the queue for a few microseconds) */
+int vh_raycast_set_timing_stride(VhRayCast* r, int enabled, uint32_t stride);
 /* 1 (default): render() splats ray intervals first; 0: march the full depth range as this fork of the reference does */
 int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled);
 

@@ -164,7 +164,12 @@ int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled)
 int vh_raycast_set_timing(VhRayCast* r, int enabled)
 {
     if (!r) return VH_ERR_BAD_ARGUMENT;
-    return guarded([&] { r->impl.setTiming(enabled != 0, enabled == 2); });
+    return guarded([&] { r->impl.setTiming(enabled != 0, enabled == 2, 1); });
+}
+int vh_raycast_set_timing_stride(VhRayCast* r, int enabled, uint32_t stride)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.setTiming(enabled != 0, enabled == 2, stride); });
 }
 
 // ---- CUDASceneRepChunkGrid ----------------------------------------------------

@@ -540,7 +540,7 @@ void CUDASceneRepHashSDF::debugHash(unsigned int report[4])
 // ---------------------------------------------------------------------------
 
 CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
-    : m_params(params), m_stream(stream), m_timer(nullptr), m_timeMarchOnly(false)
+    : m_params(params), m_stream(stream), m_timer(nullptr), m_timeMarchOnly(false), m_timeStride(1), m_renderCalls(0)
 {
     std::memset(&m_data, 0, sizeof(m_data));
     const size_t n = (size_t)params.m_width * params.m_height;
@@ -570,9 +570,10 @@ CUDARayCastSDF::~CUDARayCastSDF()
     if (d_tileBlocks) (void)hipFree(d_tileBlocks);
 }
 
-void CUDARayCastSDF::setTiming(bool on, bool marchOnly)
+void CUDARayCastSDF::setTiming(bool on, bool marchOnly, unsigned int stride)
 {
     m_timeMarchOnly = marchOnly;
+    m_timeStride = stride ? stride : 1u;
     if (on && !m_timer) m_timer = new VhStageTimer(3);
     if (!on && m_timer) { delete m_timer; m_timer = nullptr; }
 }
@@ -597,21 +598,24 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     std::memcpy(m_params.m_viewMatrix, view.m, sizeof(view.m));
     std::memcpy(m_params.m_viewMatrixInverse, lastRigidTransform.m, sizeof(lastRigidTransform.m));
 
+    // an event record idles the queue for a few microseconds: with a stride only every n-th call is timed
+    const bool timed = m_timer && (m_renderCalls++ % m_timeStride) == 0;
+    const bool timedAll = timed && !m_timeMarchOnly;
     if (m_useIntervals) {
-        if (m_timer && !m_timeMarchOnly) m_timer->start(ST_SPLAT, (hipStream_t)m_stream);
+        if (timedAll) m_timer->start(ST_SPLAT, (hipStream_t)m_stream);
         check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "rayIntervalSplatCUDA");
-        if (m_timer && !m_timeMarchOnly) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
+        if (timedAll) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
     }
-    if (m_timer) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
+    if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
     if (m_useIntervals) {
         check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "renderCS");
     } else {
         check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
     }
-    if (m_timer) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
+    if (timed) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {
-        if (m_timer && !m_timeMarchOnly) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
+        if (timedAll) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
         check(vh_compute_normals(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, m_stream), "computeNormals");
-        if (m_timer && !m_timeMarchOnly) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
+        if (timedAll) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
     }
 }

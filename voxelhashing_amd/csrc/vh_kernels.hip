@@ -407,18 +407,30 @@ __global__ __launch_bounds__(256) void k_gc_free(VhHashData hd, VhHashParams hp,
 // probing the hash table in HBM (and a block missing from the list is unallocated, as a failed probe would say).
 // ---------------------------------------------------------------------------
 
-constexpr uint32_t kSplatWordsPerWave = 8;
+constexpr uint32_t kSplatWordsPerGroup = 32; // occupancy words (x32 buckets) per workgroup
+constexpr uint32_t kSplatQueue = 128;        // blocks a workgroup queues per round
 
+// (i / nx, i % nx) for i < 2^22 without the integer-division sequence: float estimate, corrected by one step
+VHD void divmod_small(uint32_t i, uint32_t nx, float rnx, uint32_t& q, uint32_t& r)
+{
+    q = (uint32_t)((float)i * rnx);
+    int rem = (int)i - (int)(q * nx);
+    if (rem < 0) { q--; rem += (int)nx; }
+    if (rem >= (int)nx) { q++; rem -= (int)nx; }
+    r = (uint32_t)rem;
+}
+
+// Three steps per workgroup, each one trip to memory: occupancy words -> bucket queue (LDS); slots of the queued
+// buckets -> block queue (LDS); one wave per queued block folds it into its tiles.  The queues balance the waves: a
+// block costs a wave a few thousand cycles, and the kernel is as long as its busiest wave.
 __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
                                                         VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap)
 {
-    // kSplatWordsPerWave occupancy words per wave: a block costs a wave a few dependent round trips (slots, then the
-    // list slot of each tile), so the fewer blocks a wave meets, the shorter the kernel; the tile loop uses all lanes
+    __shared__ uint32_t sBuckets[kSplatWordsPerGroup * 32];
+    __shared__ int4 sBlocks[kSplatQueue];
+    __shared__ uint32_t sNumBuckets, sNumBlocks;
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
-    const uint32_t lane = lane_id();
-    const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    const uint32_t wordIdx = wave * kSplatWordsPerWave + lane;
-    const uint32_t myBits = (lane < kSplatWordsPerWave && wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
+    const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
     const int tilesX = (int)((rp.m_width + 7) / 8), tilesY = (int)((rp.m_height + 7) / 8);
     const float vs = hp.m_virtualVoxelSize;
     // voxel indices a sample at p can read along one axis: floor(p/vs) and floor(p/vs)+1 (+-1/2 more for the
@@ -426,69 +438,84 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
     // voxel on top covers every rounding on the way (|p/vs| < 2^16 where the quotient is resolved to 2^-8).
     const float growLo = (rp.m_useGradients ? 1.75f : 1.25f) * vs, growHi = (rp.m_useGradients ? 0.75f : 0.25f) * vs;
 
-    uint64_t pending = __ballot(myBits != 0u);
-    while (pending) { // wave-uniform loops: one bucket, then one block, at a time, the 64 lanes share its tiles
-        const int src = __ffsll((long long)pending) - 1;
-        pending &= pending - 1ull;
-        uint32_t w = (uint32_t)__shfl((int)myBits, src);
-        const uint32_t wi = (uint32_t)__shfl((int)wordIdx, src);
-        while (w) {
-            const uint32_t bucket = wi * 32u + (uint32_t)(__ffs((int)w) - 1);
-            w &= w - 1u;
-            int4 q = make_int4(0, 0, 0, VH_FREE_ENTRY);
-            if (lane < VH_HASH_BUCKET_SIZE) q = load_quad(&hd.d_hash[(uint64_t)bucket * VH_HASH_BUCKET_SIZE + lane]);
-            uint64_t alloc = __ballot(q.w != VH_FREE_ENTRY);
-            while (alloc) {
-                const int sl = __ffsll((long long)alloc) - 1;
-                alloc &= alloc - 1ull;
-                const int bx = __shfl(q.x, sl), by = __shfl(q.y, sl), bz = __shfl(q.z, sl), ptr = __shfl(q.w, sl);
-                const float lox = (float)(bx * VH_SDF_BLOCK_SIZE) * vs - growLo, hix = (float)(bx * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
-                const float loy = (float)(by * VH_SDF_BLOCK_SIZE) * vs - growLo, hiy = (float)(by * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
-                const float loz = (float)(bz * VH_SDF_BLOCK_SIZE) * vs - growLo, hiz = (float)(bz * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
-                float zmin = pinf(), zmax = minf(), xmin = pinf(), xmax = minf(), ymin = pinf(), ymax = minf();
+    if (threadIdx.x == 0) { sNumBuckets = 0u; sNumBlocks = 0u; }
+    __syncthreads();
+    // 1: occupied buckets of this group's words
+    if (threadIdx.x < kSplatWordsPerGroup) {
+        const uint32_t wordIdx = blockIdx.x * kSplatWordsPerGroup + threadIdx.x;
+        uint32_t bits = wordIdx < nWords ? hd.d_bucketBits[wordIdx] : 0u;
+        while (bits) {
+            const uint32_t bucket = wordIdx * 32u + (uint32_t)(__ffs((int)bits) - 1);
+            bits &= bits - 1u;
+            sBuckets[atomicAdd(&sNumBuckets, 1u)] = bucket;
+        }
+    }
+    __syncthreads();
+    const uint32_t nBuckets = sNumBuckets;
+    // 2+3 in rounds of 12 buckets (120 slots, within the block queue)
+    for (uint32_t b0 = 0; b0 < nBuckets; b0 += 12u) {
+        const uint32_t bi = b0 + threadIdx.x / 16u, sl = threadIdx.x % 16u;
+        if (threadIdx.x < 12u * 16u && bi < nBuckets && sl < VH_HASH_BUCKET_SIZE) {
+            const int4 q = load_quad(&hd.d_hash[(uint64_t)sBuckets[bi] * VH_HASH_BUCKET_SIZE + sl]);
+            if (q.w != VH_FREE_ENTRY) sBlocks[atomicAdd(&sNumBlocks, 1u)] = q;
+        }
+        __syncthreads();
+        const uint32_t nBlocks = sNumBlocks;
+        for (uint32_t k = wave; k < nBlocks; k += 256 / kWave) {
+            const int4 q = sBlocks[k];
+            const int bx = q.x, by = q.y, bz = q.z, ptr = q.w;
+            const float lox = (float)(bx * VH_SDF_BLOCK_SIZE) * vs - growLo, hix = (float)(bx * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+            const float loy = (float)(by * VH_SDF_BLOCK_SIZE) * vs - growLo, hiy = (float)(by * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+            const float loz = (float)(bz * VH_SDF_BLOCK_SIZE) * vs - growLo, hiz = (float)(bz * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+            float zmin = pinf(), zmax = minf(), xmin = pinf(), xmax = minf(), ymin = pinf(), ymax = minf();
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const F3 pc = mat_mul_p(rp.m_viewMatrix, mk3((c & 1) ? hix : lox, (c & 2) ? hiy : loy, (c & 4) ? hiz : loz));
-                    zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
-                    const float iz = 1.0f / fmaxf(pc.z, 1e-6f);
-                    const float sx = pc.x * cp.fx * iz + cp.mx, sy = pc.y * cp.fy * iz + cp.my;
-                    xmin = fminf(xmin, sx); xmax = fmaxf(xmax, sx);
-                    ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy);
-                }
-                if (!(zmax > 0.0f)) continue; // entirely behind the camera: no sample (depth > 0) lies in it
-                int tx0 = 0, ty0 = 0, tx1 = tilesX - 1, ty1 = tilesY - 1;
-                if (zmin > 0.05f) { // box in front of the camera; otherwise it may project anywhere: every tile
-                    const float slop = 1.0f + 1e-3f * fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax)));
-                    // clamp in float first: the float -> int conversion of a huge coordinate is not defined
-                    tx0 = (int)fminf(fmaxf(floorf((xmin - slop) * 0.125f), 0.0f), (float)tilesX);
-                    ty0 = (int)fminf(fmaxf(floorf((ymin - slop) * 0.125f), 0.0f), (float)tilesY);
-                    tx1 = (int)fminf(fmaxf(floorf((xmax + slop) * 0.125f), -1.0f), (float)(tilesX - 1));
-                    ty1 = (int)fminf(fmaxf(floorf((ymax + slop) * 0.125f), -1.0f), (float)(tilesY - 1));
-                }
-                if (tx1 < tx0 || ty1 < ty0) continue; // off screen
-                const float zs = 1e-3f * fabsf(zmax) + 0.5f * vs;
-                const uint32_t lo = __float_as_uint(fmaxf(zmin - zs, 0.0f)), hi = __float_as_uint(fmaxf(zmax + zs, 0.0f));
-                const uint32_t nx = (uint32_t)(tx1 - tx0 + 1), n = nx * (uint32_t)(ty1 - ty0 + 1);
-                for (uint32_t base = 0; base < n; base += 4u * kWave) {
-                    // four tiles per lane in flight: the list slots come back from L2 together
-                    uint32_t t[4], slot[4];
+            for (int c = 0; c < 8; c++) {
+                const F3 pc = mat_mul_p(rp.m_viewMatrix, mk3((c & 1) ? hix : lox, (c & 2) ? hiy : loy, (c & 4) ? hiz : loz));
+                zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
+                const float iz = 1.0f / fmaxf(pc.z, 1e-6f);
+                const float sx = pc.x * cp.fx * iz + cp.mx, sy = pc.y * cp.fy * iz + cp.my;
+                xmin = fminf(xmin, sx); xmax = fmaxf(xmax, sx);
+                ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy);
+            }
+            if (!(zmax > 0.0f)) continue; // entirely behind the camera: no sample (depth > 0) lies in it
+            int tx0 = 0, ty0 = 0, tx1 = tilesX - 1, ty1 = tilesY - 1;
+            if (zmin > 0.05f) { // box in front of the camera; otherwise it may project anywhere: every tile
+                const float slop = 1.0f + 1e-3f * fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax)));
+                // clamp in float first: the float -> int conversion of a huge coordinate is not defined
+                tx0 = (int)fminf(fmaxf(floorf((xmin - slop) * 0.125f), 0.0f), (float)tilesX);
+                ty0 = (int)fminf(fmaxf(floorf((ymin - slop) * 0.125f), 0.0f), (float)tilesY);
+                tx1 = (int)fminf(fmaxf(floorf((xmax + slop) * 0.125f), -1.0f), (float)(tilesX - 1));
+                ty1 = (int)fminf(fmaxf(floorf((ymax + slop) * 0.125f), -1.0f), (float)(tilesY - 1));
+            }
+            if (tx1 < tx0 || ty1 < ty0) continue; // off screen
+            const float zs = 1e-3f * fabsf(zmax) + 0.5f * vs;
+            const uint32_t lo = __float_as_uint(fmaxf(zmin - zs, 0.0f)), hi = __float_as_uint(fmaxf(zmax + zs, 0.0f));
+            const uint32_t nx = (uint32_t)(tx1 - tx0 + 1), n = nx * (uint32_t)(ty1 - ty0 + 1);
+            const float rnx = 1.0f / (float)nx;
+            constexpr uint32_t kInFlight = 4; // tiles per lane in flight: the list slots come back from L2 together
+            for (uint32_t base = 0; base < n; base += kInFlight * kWave) {
+                uint32_t t[kInFlight], slot[kInFlight];
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; j++) {
-                        const uint32_t i = base + j * kWave + lane;
-                        t[j] = (uint32_t)(ty0 + (int)(i / nx)) * (uint32_t)tilesX + (uint32_t)(tx0 + (int)(i % nx));
-                        slot[j] = 0xffffffffu;
-                        if (i < n) {
-                            slot[j] = atomicAdd(&heads[t[j]].z, 1u);
-                            atomicMin(&heads[t[j]].x, lo);
-                            atomicMax(&heads[t[j]].y, hi);
-                        }
+                for (uint32_t j = 0; j < kInFlight; j++) {
+                    const uint32_t i = base + j * kWave + lane;
+                    uint32_t qy, qx;
+                    divmod_small(i, nx, rnx, qy, qx);
+                    t[j] = (uint32_t)(ty0 + (int)qy) * (uint32_t)tilesX + (uint32_t)(tx0 + (int)qx);
+                    slot[j] = 0xffffffffu;
+                    if (i < n) {
+                        slot[j] = atomicAdd(&heads[t[j]].z, 1u);
+                        atomicMin(&heads[t[j]].x, lo);
+                        atomicMax(&heads[t[j]].y, hi);
                     }
-#pragma unroll
-                    for (uint32_t j = 0; j < 4u; j++)
-                        if (slot[j] < cap) lists[(size_t)t[j] * cap + slot[j]] = make_int4(bx, by, bz, ptr);
                 }
+#pragma unroll
+                for (uint32_t j = 0; j < kInFlight; j++)
+                    if (slot[j] < cap) lists[(size_t)t[j] * cap + slot[j]] = make_int4(bx, by, bz, ptr);
             }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) sNumBlocks = 0u;
+        __syncthreads();
     }
 }
 
@@ -1398,7 +1425,7 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
     if (!hd || !hp || !cp || !rp || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     if (rp->m_width == 0 || rp->m_height == 0) return VH_OK;
     const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
-    k_interval_splat<<<cdiv(cdiv(nWords, kSplatWordsPerWave), 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
+    k_interval_splat<<<cdiv(nWords, kSplatWordsPerGroup), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
                                                                        reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u);
     return vh_last_launch_error();
 }

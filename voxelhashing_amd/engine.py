@@ -212,8 +212,8 @@ class CUDARayCastSDF:
         check(self.L.vh_raycast_get_params(self.handle, C.byref(rp)), "getRayCastParams")
         return rp
 
-    def setTiming(self, on, march_only=False):
-        check(self.L.vh_raycast_set_timing(self.handle, (2 if march_only else 1) if on else 0), "setTiming")
+    def setTiming(self, on, march_only=False, stride=1):
+        check(self.L.vh_raycast_set_timing_stride(self.handle, (2 if march_only else 1) if on else 0, stride), "setTiming")
 
     def setIntervalSplatting(self, on):
         check(self.L.vh_raycast_set_interval_splatting(self.handle, 1 if on else 0), "setIntervalSplatting")
