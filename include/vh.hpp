@@ -164,6 +164,8 @@ private:
     unsigned int m_timeStride, m_renderCalls;
     uint32_t* d_tileHeads;     // {min, max camera depth, block count, 0} per 8x8-pixel tile
     VhTileBlock* d_tileBlocks; // VH_TILE_LIST_CAPACITY blocks per tile
+    uint32_t* d_schedule;      // tiles by cost class, for the launch order of the next render()
+    uint32_t m_phase;          // render() calls with intervals so far
     bool m_useIntervals;
 };
 

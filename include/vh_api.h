@@ -112,10 +112,17 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
  * bit-identical maps.  vh_render_intervals consumes and re-arms the heads; vh_ray_interval_clear arms them once. */
 int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height, vhStream_t stream);
 int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, const VhRayCastParams* rp,
-                          uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, vhStream_t stream);
+                          uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, uint32_t* d_schedule, uint32_t phase,
+                          vhStream_t stream);
+/* d_schedule (may be NULL) is vh_render_schedule_bytes() of device memory, zeroed once, that belongs to one sequence
+ * of splat + render calls; phase is that sequence's call counter (1, 2, 3, ...; the same value for the splat and the
+ * render of one frame).  The ray caster stores the cost every tile had; the next splat sorts the tiles by it and
+ * deals them to the workgroups so that the compute units get even loads.  The maps do not depend on it, and a render
+ * whose splat was given no schedule uses raster order. */
+size_t vh_render_schedule_bytes(uint32_t width, uint32_t height);
 int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
                         const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
-                        vhStream_t stream);
+                        uint32_t* d_schedule, uint32_t phase, vhStream_t stream);
 /* computeNormals(float4* d_output, float4* d_input, width, height)  DSC/CameraUtil.cu:699 */
 int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream);
 

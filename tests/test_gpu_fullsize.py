@@ -94,9 +94,9 @@ def test_interval_splatting_does_not_change_a_bit(vh, cfg, scene_name):
         hd, hpp, rpp, rd = scene.getHashData(), scene.getHashParams(), full.getRayCastParams(), full.getRayCastData()
         for cap, blocks in ((3, small_lists), (0, None)):
             lib.check(L.vh_ray_interval_splat(C.byref(hd), C.byref(hpp), C.byref(cp), C.byref(rpp), heads.ptr,
-                                              blocks.ptr if blocks else None, cap, None))
+                                              blocks.ptr if blocks else None, cap, None, 0, None))
             lib.check(L.vh_render_intervals(C.byref(hd), C.byref(hpp), C.byref(rd), C.byref(cp), C.byref(rpp), heads.ptr,
-                                            blocks.ptr if blocks else None, cap, None))
+                                            blocks.ptr if blocks else None, cap, None, 0, None))
             mc = full.download()
             for k in ("depth", "depth4", "colors"):  # normals are computeNormals' output of the class-level call
                 assert np.array_equal(mc[k].view(np.uint32), mb[k].view(np.uint32)), f"view {i} capacity {cap}: {k}"

@@ -556,6 +556,11 @@ CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
     checkHip(hipMalloc((void**)&d_tileHeads, sizeof(uint32_t) * 4 * (tiles ? tiles : 1)), "tile heads");
     checkHip(hipMalloc((void**)&d_tileBlocks, sizeof(VhTileBlock) * VH_TILE_LIST_CAPACITY * (tiles ? tiles : 1)), "tile block lists");
     check(vh_ray_interval_clear(d_tileHeads, params.m_width, params.m_height, m_stream), "vh_ray_interval_clear");
+    d_schedule = nullptr;
+    m_phase = 0;
+    const size_t schedBytes = vh_render_schedule_bytes(params.m_width, params.m_height);
+    checkHip(hipMalloc((void**)&d_schedule, schedBytes), "render schedule");
+    checkHip(hipMemsetAsync(d_schedule, 0, schedBytes, (hipStream_t)m_stream), "render schedule");
 }
 
 CUDARayCastSDF::~CUDARayCastSDF()
@@ -568,6 +573,7 @@ CUDARayCastSDF::~CUDARayCastSDF()
     if (m_data.d_colors) (void)hipFree(m_data.d_colors);
     if (d_tileHeads) (void)hipFree(d_tileHeads);
     if (d_tileBlocks) (void)hipFree(d_tileBlocks);
+    if (d_schedule) (void)hipFree(d_schedule);
 }
 
 void CUDARayCastSDF::setTiming(bool on, bool marchOnly, unsigned int stride)
@@ -603,12 +609,13 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     const bool timedAll = timed && !m_timeMarchOnly;
     if (m_useIntervals) {
         if (timedAll) m_timer->start(ST_SPLAT, (hipStream_t)m_stream);
-        check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "rayIntervalSplatCUDA");
+        ++m_phase;
+        check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, d_schedule, m_phase, m_stream), "rayIntervalSplatCUDA");
         if (timedAll) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
     }
     if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
     if (m_useIntervals) {
-        check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, m_stream), "renderCS");
+        check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, d_schedule, m_phase, m_stream), "renderCS");
     } else {
         check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
     }

@@ -423,8 +423,93 @@ VHD void divmod_small(uint32_t i, uint32_t nx, float rnx, uint32_t& q, uint32_t&
 // Three steps per workgroup, each one trip to memory: occupancy words -> bucket queue (LDS); slots of the queued
 // buckets -> block queue (LDS); one wave per queued block folds it into its tiles.  The queues balance the waves: a
 // block costs a wave a few thousand cycles, and the kernel is as long as its busiest wave.
+// Cost of a tile in units of one empty-space step; a full sample (8 taps) weighs kCostSample of them.  The wave's
+// cost is its busiest lane's: k_render stores the tile's cost class for the next frame's launch order.
+constexpr uint32_t kCostSample = 6;
+constexpr uint32_t kCostClasses = 16;
+constexpr uint32_t kCostClassWidth = 16;
+
+// Launch order of the next k_render (one workgroup of k_interval_splat, beside the others): tiles sorted by the cost
+// class the previous k_render stored, dearest first, dealt to the workgroups (4 tiles each) in rows of numCUs that
+// alternate direction.  The hardware places workgroup g on compute unit g mod numCUs (all of them are resident), so
+// a compute unit receives one workgroup of every row: the dearest of one row with the cheapest of the next.
+__device__ void schedule_tiles(uint32_t* sched, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t* sCount /*[2 * 16 * kCostClasses]*/)
+{
+    // layout: {phase the slots were made for, -, -, -}, cost class per tile, {tile, phase} per launch slot
+    const uint32_t* cls = sched + 4;
+    uint2* slots = reinterpret_cast<uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u));
+    if (threadIdx.x == 0) sched[0] = phase;
+    // counting sort with kSub sub-bins per class (keyed by the thread): 64 lanes adding to one LDS word serialise
+    constexpr uint32_t kSub = 16, kBins = kCostClasses * kSub;
+    for (uint32_t i = threadIdx.x; i < 2u * kBins; i += blockDim.x) sCount[i] = 0u;
+    __syncthreads();
+    const uint32_t sub = threadIdx.x % kSub;
+    // four tiles per load, kBatch loads in flight: this workgroup is alone with its trips to memory
+    constexpr uint32_t kBatch = 5;
+    const uint32_t nQuads = (nTiles + 3u) / 4u; // the cost array is padded to whole quads (vh_render_schedule_bytes)
+    const uint4* cls4 = reinterpret_cast<const uint4*>(cls);
+    for (uint32_t q0 = threadIdx.x; q0 < nQuads; q0 += blockDim.x * kBatch) {
+        uint4 c[kBatch];
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; j++) {
+            const uint32_t q = q0 + j * blockDim.x;
+            c[j] = q < nQuads ? cls4[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; j++) {
+            const uint32_t t = (q0 + j * blockDim.x) * 4u;
+            if (t + 0u < nTiles) atomicAdd(&sCount[min(c[j].x, kCostClasses - 1u) * kSub + sub], 1u);
+            if (t + 1u < nTiles) atomicAdd(&sCount[min(c[j].y, kCostClasses - 1u) * kSub + sub], 1u);
+            if (t + 2u < nTiles) atomicAdd(&sCount[min(c[j].z, kCostClasses - 1u) * kSub + sub], 1u);
+            if (t + 3u < nTiles) atomicAdd(&sCount[min(c[j].w, kCostClasses - 1u) * kSub + sub], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWave) { // start of each bin in the sorted order, dearest class first: one wave scans the 256 bins
+        const uint32_t lane = threadIdx.x;
+        uint32_t n[4], mine = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) { n[j] = sCount[kBins - 1u - (lane * 4u + j)]; mine += n[j]; } // bins in descending order
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < (int)kWave; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if ((int)lane >= off) incl += up;
+        }
+        uint32_t start = incl - mine;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) { sCount[kBins + kBins - 1u - (lane * 4u + j)] = start; start += n[j]; }
+    }
+    __syncthreads();
+    const uint32_t nGroups = (nTiles + 3u) / 4u, fullRows = nGroups / numCUs;
+    for (uint32_t q0 = threadIdx.x; q0 < nQuads; q0 += blockDim.x * kBatch) {
+        uint4 c[kBatch];
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; j++) {
+            const uint32_t q = q0 + j * blockDim.x;
+            c[j] = q < nQuads ? cls4[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; j++) {
+            const uint32_t cc[4] = { c[j].x, c[j].y, c[j].z, c[j].w };
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t t = (q0 + j * blockDim.x) * 4u + k;
+                if (t < nTiles) {
+                    const uint32_t i = atomicAdd(&sCount[kBins + min(cc[k], kCostClasses - 1u) * kSub + sub], 1u); // rank of tile t
+                    uint32_t g = i / 4u;
+                    const uint32_t row = g / numCUs, col = g % numCUs;
+                    if ((row & 1u) && row < fullRows) g = row * numCUs + (numCUs - 1u - col);
+                    slots[g * 4u + (i & 3u)] = make_uint2(t, phase);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
-                                                        VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap)
+                                                        VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap,
+                                                        uint32_t* sched, uint32_t phase, uint32_t numCUs, uint32_t nSplatGroups)
 {
     __shared__ uint32_t sBuckets[kSplatWordsPerGroup * 32];
     __shared__ int4 sBlocks[kSplatQueue];
@@ -438,6 +523,10 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
     // voxel on top covers every rounding on the way (|p/vs| < 2^16 where the quotient is resolved to 2^-8).
     const float growLo = (rp.m_useGradients ? 1.75f : 1.25f) * vs, growHi = (rp.m_useGradients ? 0.75f : 0.25f) * vs;
 
+    if (blockIdx.x >= nSplatGroups) { // the extra workgroup (launched only with a schedule)
+        schedule_tiles(sched, (uint32_t)(tilesX * tilesY), phase, numCUs, sBuckets);
+        return;
+    }
     if (threadIdx.x == 0) { sNumBuckets = 0u; sNumBlocks = 0u; }
     __syncthreads();
     // 1: occupied buckets of this group's words
@@ -585,17 +674,47 @@ constexpr uint32_t kTileTabSlots = 2 * VH_TILE_LIST_CAPACITY; // LDS table per w
 
 // block -> voxel pointer through the hash table in HBM
 struct HashLookup {
-    static constexpr bool kResolvesFirstTap = false;
     const VhHashData& hd;
     const VhHashParams& hp;
     HashMod hm;
     BlockCache bc;
     VHD int find(int bx, int by, int bz) { return cached_lookup(hd, hp, hm, bc, bx, by, bz); }
     // may the sample whose first tap lies in this block be valid?  (occupancy bit of the bucket: one cached dword)
-    VHD bool first_tap(int bx, int by, int bz, int& p0)
+    VHD bool first_tap(int bx, int by, int bz, int& handle)
     {
-        p0 = kPtrUnknown;
+        handle = kPtrUnknown;
         return bucket_maybe_occupied(hd, hash_pos_fast(hm, mki3(bx, by, bz)));
+    }
+    // voxel pointers of the eight taps (p[j]: bit0 = x1, bit1 = y1, bit2 = z1), one probe per DISTINCT block;
+    // false if one of the blocks does not exist.  bit a of `straddle`: the tap pair along axis a lies in two blocks.
+    VHD bool resolve(int, int bxa, int bya, int bza, int bxb, int byb, int bzb, uint32_t straddle, int (&p)[8])
+    {
+        const int p0 = find(bxa, bya, bza);
+        if (p0 == VH_FREE_ENTRY) return false; // the first tap reads the zero voxel (weight 0)
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j] = p0;
+        if (straddle) {
+            uint32_t need = 0xfeu; // combos whose block differs from combo 0 still need a pointer
+#pragma unroll
+            for (uint32_t j = 1; j < 8u; j++)
+                if ((j & straddle) == 0u) need &= ~(1u << j);
+#pragma unroll 1
+            while (need) {
+                const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
+                const int pk = find((k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
+                if (pk == VH_FREE_ENTRY) return false;
+                const uint32_t km = k & straddle;
+                uint32_t same = 0u;
+#pragma unroll
+                for (uint32_t j = 1; j < 8u; j++) {
+                    const bool eq = (j & straddle) == km;
+                    p[j] = eq ? pk : p[j];
+                    same |= (eq ? 1u : 0u) << j;
+                }
+                need &= ~same;
+            }
+        }
+        return true;
     }
 };
 
@@ -604,35 +723,73 @@ __device__ __noinline__ int lookup_ptr_slow(const VhHashData hd, const VhHashPar
     return lookup_ptr(hd, hp, mki3(bx, by, bz));
 }
 
-// block -> voxel pointer through the tile's own table in LDS (open addressing, built from the tile's block list).
+// block -> voxel pointers through the tile's own table in LDS, built from the tile's block list (open addressing).
+// A slot is kTileSlotWords words: {x, y, z, p000, p100, p010, p110, p001, p101, p011, p111, -}: the block, its voxel
+// pointer and the pointers of its seven +x/+y/+z neighbours (VH_FREE_ENTRY where there is none), so that a sample
+// resolves its eight taps with one probe and one round of LDS reads, however many blocks they straddle.
 // k_interval_splat lists every block the tile's rays can read, so a block that is not in a COMPLETE table is not
 // allocated; when the list overflowed, the table holds a part of it and a miss falls back to the hash table.
+constexpr uint32_t kTileSlotWords = 12;
+
 struct TileLookup {
-    static constexpr bool kResolvesFirstTap = true;
-    const int4* tab;
+    const int* tab;
     bool complete;
     const VhHashData& hd;
     const VhHashParams& hp;
     VHD static uint32_t slot_of(int bx, int by, int bz)
     {
-        return ((uint32_t)bx * 73856093u ^ (uint32_t)by * 19349669u ^ (uint32_t)bz * 83492791u) & (kTileTabSlots - 1u);
+        // blocks of a tile are neighbours along a beam: a small linear hash spreads them (a 5x5x5 cube maps 1:1)
+        return (uint32_t)(bx + 5 * by + 24 * bz) & (kTileTabSlots - 1u); // shifts and adds only
     }
-    VHD int find(int bx, int by, int bz) const
+    VHD static int slot_find(const int* tab, int bx, int by, int bz)
     {
         uint32_t h = slot_of(bx, by, bz);
-        int4 e;
         for (;;) {
-            e = tab[h]; // one 16-byte LDS read; all four words decide (no short circuit: it would split the read)
-            if ((int)(e.w == VH_FREE_ENTRY) | ((int)(e.x == bx) & (int)(e.y == by) & (int)(e.z == bz))) break;
+            const int4 e = *reinterpret_cast<const int4*>(&tab[h * kTileSlotWords]); // one 16-byte LDS read
+            if (e.w == VH_FREE_ENTRY) return -1;
+            if ((int)(e.x == bx) & (int)(e.y == by) & (int)(e.z == bz)) return (int)h;
             h = (h + 1u) & (kTileTabSlots - 1u);
         }
-        if (e.w == VH_FREE_ENTRY && !complete) return lookup_ptr(hd, hp, mki3(bx, by, bz));
-        return e.w;
     }
-    VHD bool first_tap(int bx, int by, int bz, int& p0) const
+    VHD int find_any(int bx, int by, int bz) const
     {
-        p0 = find(bx, by, bz);
-        return p0 != VH_FREE_ENTRY;
+        const int sl = slot_find(tab, bx, by, bz);
+        if (sl >= 0) return tab[(uint32_t)sl * kTileSlotWords + 3u];
+        return complete ? VH_FREE_ENTRY : lookup_ptr(hd, hp, mki3(bx, by, bz));
+    }
+    // handle: the slot of the block (>= 0), or kPtrUnknown
+    VHD bool first_tap(int bx, int by, int bz, int& handle) const
+    {
+        handle = slot_find(tab, bx, by, bz);
+        if (handle >= 0) return true;
+        handle = kPtrUnknown;
+        return complete ? false : lookup_ptr(hd, hp, mki3(bx, by, bz)) != VH_FREE_ENTRY;
+    }
+    VHD bool resolve(int handle, int bxa, int bya, int bza, int bxb, int byb, int bzb, uint32_t straddle, int (&p)[8]) const
+    {
+        if (complete) {
+            const int sl = handle >= 0 ? handle : slot_find(tab, bxa, bya, bza);
+            if (sl < 0) return false; // the first tap reads the zero voxel (weight 0)
+            // the tap pair of an axis lies in one block or in two adjacent ones: combo j reads neighbour (j & straddle)
+            const int* e = &tab[(uint32_t)sl * kTileSlotWords + 3u];
+            int all = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) {
+                p[j] = e[j & straddle];
+                all |= p[j];
+            }
+            return all >= 0; // voxel pointers are >= 0, VH_FREE_ENTRY is not
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) p[k] = 0;
+#pragma unroll 1
+        for (uint32_t j = 0; j < 8u; j++) {
+            const int pj = find_any((j & 1u) ? bxb : bxa, (j & 2u) ? byb : bya, (j & 4u) ? bzb : bza);
+            if (pj == VH_FREE_ENTRY) return false;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) p[k] = (k == j) ? pj : p[k];
+        }
+        return true;
     }
 };
 
@@ -640,11 +797,19 @@ struct TileLookup {
 // two words, and the sdf word is then fetched only after the weight test -- a second trip to memory per sample.
 VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 {
+#if defined(VH_EXP) && VH_EXP == 2
+    return make_uint2(__float_as_uint(0.05f - 0.01f * (float)((ptr >> 9) & 7) + 0.001f * (float)(lx + ly + lz)), 0x10808080u);
+#endif
     const unsigned long long v = __hip_atomic_load(
         reinterpret_cast<const unsigned long long*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]),
         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
+
+struct Taps {
+    int x0, y0, z0, x1, y1, z1;       // voxel coordinates of the lower / upper tap per axis
+    int bxa, bya, bza, bxb, byb, bzb; // their SDF blocks (virtualVoxelPosToSDFBlock)
+};
 
 // trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116, for tap
 // voxel coordinates (x0..z1) the caller has already resolved.
@@ -655,42 +820,18 @@ VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 // the reference computes it for every sample but reads it only from the last
 // bisection sample (RayCastSDFUtil.h:231,241).
 template <bool COLOR, class LK>
-VHD bool trilinear(const VhHashData& hd, float vs, LK& lk, int p0in, int x0, int y0, int z0, int x1, int y1, int z1,
+VHD bool trilinear(const VhHashData& hd, float vs, LK& lk, int p0in, const Taps& tp,
                    F3 pos, float rvs, float& dist, uint32_t& colorOut)
 {
-    const int bxa = vvp_to_block1(x0), bya = vvp_to_block1(y0), bza = vvp_to_block1(z0);
-    const int bxb = vvp_to_block1(x1), byb = vvp_to_block1(y1), bzb = vvp_to_block1(z1);
+    const int x0 = tp.x0, y0 = tp.y0, z0 = tp.z0, x1 = tp.x1, y1 = tp.y1, z1 = tp.z1;
+    const int bxa = tp.bxa, bya = tp.bya, bza = tp.bza, bxb = tp.bxb, byb = tp.byb, bzb = tp.bzb;
     // bit a of `straddle`: the tap pair along axis a lies in two different blocks
     const uint32_t straddle = (bxb != bxa ? 1u : 0u) | (byb != bya ? 2u : 0u) | (bzb != bza ? 4u : 0u);
 
-    // block pointer per tap combo (bit0 = x1, bit1 = y1, bit2 = z1); one probe per DISTINCT block
-    int p0 = (LK::kResolvesFirstTap && p0in != kPtrUnknown) ? p0in : lk.find(bxa, bya, bza);
-    if (p0 == VH_FREE_ENTRY) return false; // the first tap reads the zero voxel (weight 0)
-    int p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
-    if (straddle) {
-        uint32_t need = 0xfeu; // combos whose block differs from combo 0 still need a pointer
-#pragma unroll
-        for (uint32_t j = 1; j < 8u; j++)
-            if ((j & straddle) == 0u) need &= ~(1u << j);
-#pragma unroll 1
-        while (need) {
-            const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
-            const int p = lk.find((k & 1u) ? bxb : bxa, (k & 2u) ? byb : bya, (k & 4u) ? bzb : bza);
-            if (p == VH_FREE_ENTRY) return false;
-            const uint32_t km = k & straddle;
-            if (((1u) & straddle) == km) p1 = p;
-            if (((2u) & straddle) == km) p2 = p;
-            if (((3u) & straddle) == km) p3 = p;
-            if (((4u) & straddle) == km) p4 = p;
-            if (((5u) & straddle) == km) p5 = p;
-            if (((6u) & straddle) == km) p6 = p;
-            if (((7u) & straddle) == km) p7 = p;
-            uint32_t same = 0u;
-#pragma unroll
-            for (uint32_t j = 1; j < 8u; j++) same |= (((j & straddle) == km) ? 1u : 0u) << j;
-            need &= ~same;
-        }
-    }
+    // voxel pointer per tap combo (bit0 = x1, bit1 = y1, bit2 = z1)
+    int p[8];
+    if (!lk.resolve(p0in, bxa, bya, bza, bxb, byb, bzb, straddle, p)) return false;
+    const int p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4], p5 = p[5], p6 = p[6], p7 = p[7];
 
     const int lx0 = x0 & 7, ly0 = y0 & 7, lz0 = z0 & 7; // = local1(): two's complement & 7 is the non-negative remainder
     const int lx1 = x1 & 7, ly1 = y1 & 7, lz1 = z1 & 7;
@@ -793,20 +934,26 @@ struct RayQ {
     float certLim; // 0.5 - margin, negative if the approximation must not be used
 };
 
-VHD void tap_coords(const RayQ& rq, float t, int& x0, int& y0, int& z0, int& x1, int& y1, int& z1)
+VHD void tap_coords(const RayQ& rq, float t, Taps& tp)
 {
     const float qx = __fmaf_rn(t, rq.dirq.x, rq.camq.x), qy = __fmaf_rn(t, rq.dirq.y, rq.camq.y), qz = __fmaf_rn(t, rq.dirq.z, rq.camq.z);
     const float gx = floorf(qx), gy = floorf(qy), gz = floorf(qz);
     const float dev = fmaxf(fmaxf(fabsf((qx - gx) - 0.5f), fabsf((qy - gy) - 0.5f)), fabsf((qz - gz) - 0.5f));
     if (dev < rq.certLim) {
-        x0 = (int)gx; y0 = (int)gy; z0 = (int)gz;
-        x1 = x0 + 1; y1 = y0 + 1; z1 = z0 + 1;
+        tp.x0 = (int)gx; tp.y0 = (int)gy; tp.z0 = (int)gz;
+        tp.x1 = tp.x0 + 1; tp.y1 = tp.y0 + 1; tp.z1 = tp.z0 + 1;
+        // |coordinates| < 2^16 here: the arithmetic shift is the reference's floor division by 8
+        tp.bxa = tp.x0 >> 3; tp.bya = tp.y0 >> 3; tp.bza = tp.z0 >> 3;
+        tp.bxb = tp.x1 >> 3; tp.byb = tp.y1 >> 3; tp.bzb = tp.z1 >> 3;
     } else {
         const F3 pd = mk3((rq.cam.x + t * rq.dir.x) - rq.halfVoxel, (rq.cam.y + t * rq.dir.y) - rq.halfVoxel, (rq.cam.z + t * rq.dir.z) - rq.halfVoxel);
-        x0 = world_to_vvp1_rb(pd.x, rq.vs, rq.rvs); y0 = world_to_vvp1_rb(pd.y, rq.vs, rq.rvs); z0 = world_to_vvp1_rb(pd.z, rq.vs, rq.rvs);
-        x1 = world_to_vvp1_rb(pd.x + rq.vs, rq.vs, rq.rvs); y1 = world_to_vvp1_rb(pd.y + rq.vs, rq.vs, rq.rvs); z1 = world_to_vvp1_rb(pd.z + rq.vs, rq.vs, rq.rvs);
+        tp.x0 = world_to_vvp1_rb(pd.x, rq.vs, rq.rvs); tp.y0 = world_to_vvp1_rb(pd.y, rq.vs, rq.rvs); tp.z0 = world_to_vvp1_rb(pd.z, rq.vs, rq.rvs);
+        tp.x1 = world_to_vvp1_rb(pd.x + rq.vs, rq.vs, rq.rvs); tp.y1 = world_to_vvp1_rb(pd.y + rq.vs, rq.vs, rq.rvs); tp.z1 = world_to_vvp1_rb(pd.z + rq.vs, rq.vs, rq.rvs);
+        tp.bxa = vvp_to_block1(tp.x0); tp.bya = vvp_to_block1(tp.y0); tp.bza = vvp_to_block1(tp.z0);
+        tp.bxb = vvp_to_block1(tp.x1); tp.byb = vvp_to_block1(tp.y1); tp.bzb = vvp_to_block1(tp.z1);
     }
 }
+
 
 struct RayHit {
     float alpha;    // ray parameter of the accepted intersection; NaN-free flag in `hit`
@@ -822,7 +969,7 @@ struct RayHit {
 // each ray's own sequence of samples is the reference's.
 template <bool GRADIENTS, class LK>
 VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
-                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayHit& out
+                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayHit& out, uint32_t& cost
 #ifdef VH_RENDER_STATS
                    , float& statTri, float& statIter
 #endif
@@ -863,7 +1010,11 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
     // (they are invalid: lastValid = 0), samples after it likewise, so nothing can be hit there.  rcur still
     // advances by the same sequence of additions, one VALU op per skipped sample.
     const float tSkip = depthToRayLength * tileZmin;
+#if defined(VH_EXP) && VH_EXP == 4
+    const float tStop = fminf(rayEnd, tSkip + 2.0f * inc);
+#else
     const float tStop = fminf(rayEnd, depthToRayLength * tileZmax);
+#endif
 #pragma unroll 1
     while (rcur < tSkip && rcur < rayEnd) rcur += inc;
 
@@ -877,16 +1028,17 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
 #pragma unroll 1
         for (;;) {
             // ---- A: skip samples whose first tap has no block (they are invalid: weight 0 at the first tap)
-            int x0, y0, z0, x1, y1, z1, p0 = kPtrUnknown;
+            Taps tp;
+            int p0 = kPtrUnknown;
             int skipped = 0;
 #pragma unroll 1
             while (rcur < tStop) {
 #ifdef VH_RENDER_STATS
                 statIter += 1024.0f / (float)__popcll(__ballot(1));
 #endif
-                tap_coords(rq, rcur, x0, y0, z0, x1, y1, z1);
-                // x >> 3 = vvp_to_block1(x): the arithmetic shift floors
-                if (lk.first_tap(x0 >> 3, y0 >> 3, z0 >> 3, p0)) break;
+                cost += 1u;
+                tap_coords(rq, rcur, tp);
+                if (lk.first_tap(tp.bxa, tp.bya, tp.bza, p0)) break;
                 skipped = 1;
                 rcur += inc;
             }
@@ -898,9 +1050,10 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
             statTri += 1.0f;
             statIter += 1.0f / (float)__popcll(__ballot(1));
 #endif
+            cost += kCostSample;
             uint32_t colorUnused = 0u;
             const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
-            const bool ok = trilinear<false>(hd, rq.vs, lk, p0, x0, y0, z0, x1, y1, z1, pos, rq.rvs, dist, colorUnused);
+            const bool ok = trilinear<false>(hd, rq.vs, lk, p0, tp, pos, rq.rvs, dist, colorUnused);
             if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) { candidate = true; break; }
             lastSdf = ok ? dist : lastSdf;
             lastAlpha = ok ? rcur : lastAlpha;
@@ -919,12 +1072,13 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
             statTri += 1.0f;
             statIter += 1.0f / (float)__popcll(__ballot(1));
 #endif
+            cost += kCostSample;
             c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
-            int cx0, cy0, cz0, cx1, cy1, cz1;
-            tap_coords(rq, c, cx0, cy0, cz0, cx1, cy1, cz1);
+            Taps ctp;
+            tap_coords(rq, c, ctp);
             const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
             float cDist = 0.0f;
-            if (!trilinear<true>(hd, rq.vs, lk, kPtrUnknown, cx0, cy0, cz0, cx1, cy1, cz1, cpos, rq.rvs, cDist, color2)) { success = false; break; }
+            if (!trilinear<true>(hd, rq.vs, lk, kPtrUnknown, ctp, cpos, rq.rvs, cDist, color2)) { success = false; break; }
             if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
             else { b = c; bDist = cDist; }
         }
@@ -1002,7 +1156,8 @@ __global__ __launch_bounds__(256) void k_render_hash(VhHashData hd, VhHashParams
     out.hit = false;
     HashLookup lk{ hd, hp, hm, {} };
     cache_init(lk.bc);
-    march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, 0.0f, pinf(), out VH_STAT_ARGS);
+    uint32_t cost = 0u;
+    march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, 0.0f, pinf(), out, cost VH_STAT_ARGS);
     store_ray(rd, cp, pix, x, y, out, GRADIENTS);
     VH_STAT_STORE
 }
@@ -1014,46 +1169,78 @@ __global__ __launch_bounds__(256) void k_render_hash(VhHashData hd, VhHashParams
 template <bool GRADIENTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
-              uint4* heads, const int4* lists, uint32_t cap)
+              uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase)
 {
-    __shared__ int4 tileTab[256 / kWave][kTileTabSlots];
+    __shared__ int tileTab[256 / kWave][kTileTabSlots * kTileSlotWords];
     const uint32_t lane = lane_id();
     const uint32_t W = rp.m_width, H = rp.m_height;
     const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
-    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    if (tile >= tilesX * tilesY) return;
-    int4* tab = tileTab[threadIdx.x / kWave];
+    const uint32_t nTiles = tilesX * tilesY;
+    const uint32_t waveIdx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave)));
+    // Launch order.  The kernel is as long as its busiest SIMD, and a SIMD's waves are the workgroups i, i+numCUs,
+    // i+2 numCUs, ... in launch order.  k_interval_splat sorts the tiles by the cost the previous frame measured
+    // (it differs little) and deals them to the workgroups so that the sums come out even.  The schedule carries the
+    // phase it was made for: one that was not refreshed for this call is ignored (raster order).
+    uint32_t tile = waveIdx;
+    if (sched && sched[0] == phase) {
+        const uint2 e = reinterpret_cast<const uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u))[waveIdx];
+        tile = e.y == phase ? e.x : nTiles; // a slot the dealing left empty (last, partial workgroup)
+    }
+    if (tile >= nTiles) return;
+    int* tab = tileTab[threadIdx.x / kWave];
+#if defined(VH_EXP) && VH_EXP == 8
+    if (tile < 0x7fffffffu) return;
+#endif
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
     const float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y);
     if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
     const uint32_t listed = min(head.z, min(cap, (uint32_t)VH_TILE_LIST_CAPACITY));
     const bool complete = listed == head.z;
-    for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i] = make_int4(0, 0, 0, VH_FREE_ENTRY);
+    int4 mine = make_int4(0, 0, 0, VH_FREE_ENTRY);
+    if (lane < listed) mine = lists[(size_t)tile * cap + lane];
+    for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i * kTileSlotWords + 3u] = VH_FREE_ENTRY;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    uint32_t h = TileLookup::slot_of(mine.x, mine.y, mine.z);
     if (lane < listed) {
-        const int4 e = lists[(size_t)tile * cap + lane];
-        uint32_t h = TileLookup::slot_of(e.x, e.y, e.z);
         // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
-        while (atomicCAS(&tab[h].w, VH_FREE_ENTRY, e.w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
-        tab[h].x = e.x; tab[h].y = e.y; tab[h].z = e.z;
+        while (atomicCAS(&tab[h * kTileSlotWords + 3u], VH_FREE_ENTRY, mine.w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
+        tab[h * kTileSlotWords + 0u] = mine.x; tab[h * kTileSlotWords + 1u] = mine.y; tab[h * kTileSlotWords + 2u] = mine.z;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < listed && complete) {
+        // pointers of the seven neighbours a sample in this block can straddle into
+#pragma unroll 1
+        for (uint32_t k = 1; k < 8u; k++) {
+            const int sl = TileLookup::slot_find(tab, mine.x + (int)(k & 1u), mine.y + (int)((k >> 1) & 1u), mine.z + (int)((k >> 2) & 1u));
+            tab[h * kTileSlotWords + 3u + k] = sl >= 0 ? tab[(uint32_t)sl * kTileSlotWords + 3u] : VH_FREE_ENTRY;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
-    if (x >= W || y >= H) return;
+    const bool inImage = x < W && y < H;
     const size_t pix = (size_t)y * W + x;
     VH_STAT_DECL
     RayHit out;
     out.hit = false;
-    if (tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
+    uint32_t cost = 0u;
+    if (inImage && tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
         TileLookup lk{ tab, complete, hd, hp };
-        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out VH_STAT_ARGS);
+        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out, cost VH_STAT_ARGS);
     }
-    store_ray(rd, cp, pix, x, y, out, GRADIENTS);
-    VH_STAT_STORE
+    if (inImage) {
+        store_ray(rd, cp, pix, x, y, out, GRADIENTS);
+        VH_STAT_STORE
+    }
+    if (sched) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cost = max(cost, (uint32_t)__shfl_xor((int)cost, off));
+        if (lane == 0) sched[4 + tile] = min(cost / kCostClassWidth, kCostClasses - 1u); // plain store: nobody waits for it
+    }
 }
 #undef VH_STAT_DECL
 #undef VH_STAT_ARGS
@@ -1395,9 +1582,15 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
     return vh_last_launch_error();
 }
 
+size_t vh_render_schedule_bytes(uint32_t width, uint32_t height)
+{
+    const size_t tiles = (size_t)cdiv(width, 8) * cdiv(height, 8);
+    return (4u + 4u * ((tiles + 3u) / 4u) + 2u * 4u * ((tiles + 3u) / 4u)) * sizeof(uint32_t); // header, cost classes, launch slots
+}
+
 int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
                         const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
-                        vhStream_t stream)
+                        uint32_t* d_schedule, uint32_t phase, vhStream_t stream)
 {
     if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
@@ -1405,8 +1598,8 @@ int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRa
     uint4* h = reinterpret_cast<uint4*>(d_tileHeads);
     const int4* l = reinterpret_cast<const int4*>(d_tileBlocks);
     const uint32_t cap = d_tileBlocks ? tileCapacity : 0u;
-    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap);
-    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap);
+    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
     return vh_last_launch_error();
 }
 
@@ -1420,13 +1613,22 @@ int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height
 }
 
 int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, const VhRayCastParams* rp,
-                          uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, vhStream_t stream)
+                          uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, uint32_t* d_schedule, uint32_t phase,
+                          vhStream_t stream)
 {
     if (!hd || !hp || !cp || !rp || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     if (rp->m_width == 0 || rp->m_height == 0) return VH_OK;
+    static int numCUs = 0; // of the current device (one device per process: INTEGRATION.md)
+    if (d_schedule && numCUs == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCUs <= 0)
+            numCUs = 256;
+    }
     const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
-    k_interval_splat<<<cdiv(nWords, kSplatWordsPerGroup), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
-                                                                       reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u);
+    const uint32_t groups = cdiv(nWords, kSplatWordsPerGroup);
+    k_interval_splat<<<groups + (d_schedule ? 1u : 0u), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
+                                                                                 reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u,
+                                                                                 d_schedule, phase, (uint32_t)(numCUs > 0 ? numCUs : 256), groups);
     return vh_last_launch_error();
 }
 
