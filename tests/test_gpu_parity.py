@@ -107,6 +107,30 @@ def test_raycast_with_gradients(E, oracle_lib):
     assert (got["normals"][..., 3] == 1.0).sum() > 500
 
 
+@pytest.mark.parametrize("width,height,params", [(100, 76, "P4"), (9, 7, "P4"), (8, 8, "P4"), (203, 149, "P2"), (64, 48, "P1")])
+def test_ray_intervals_on_ragged_image_sizes(E, oracle_lib, width, height, params):
+    """tile lists / depth intervals / launch schedule with partial tiles and a partial last workgroup, fine voxels
+    (long lists) and several renders in a row (the schedule is live from the second one): == oracle, == full range"""
+    ps = synth.PARAM_SETS[params]
+    hp = T.make_hash_params(1 << 14, 1 << 13, **ps)
+    cp = T.make_depth_camera_params(width, height)
+    rp = T.make_raycast_params(hp, cp)
+    opt = T.make_scene_options(offline=True, gc=False)
+    poses = [synth.orbit_pose(k, n_frames=60) for k in range(4)]
+    g, r, o = run_pair(E, oracle_lib, hp, cp, rp, opt, poses, synth.S1_SPHERES, check_each=False)
+    full = E.CUDARayCastSDF(rp)
+    full.setIntervalSplatting(False)
+    hits = 0
+    for k in (3, 1, 2, 3, 0):
+        r.render(g.getHashData(), g.getHashParams(), cp, poses[k])
+        full.render(g.getHashData(), g.getHashParams(), cp, poses[k])
+        got = r.download()
+        assert_maps_equal(got, full.download(), f"{width}x{height} view {k}: intervals vs full range")
+        assert_maps_equal(got, o.render(poses[k]), f"{width}x{height} view {k}: vs oracle")
+        hits += int((got["depth"] != -np.inf).sum())
+    assert hits > 0.2 * width * height
+
+
 @pytest.mark.parametrize("voxel,buckets", [(0.04, 500000), (0.01, 2000000), (0.02, 1 << 18), (0.004, 1 << 14), (0.035, 7)])
 def test_exact_shortcuts(vh, voxel, buckets):
     """div_exact == `/` and umod_fast == `%` bit for bit on 16 M pseudo-random operands"""
