@@ -233,6 +233,8 @@ public:
     bool isChunkInSphere(const vh::vec3i& chunk, const vh::vec3f& center, float radius) const; // .h:317
     bool containsSDFBlocksChunkInRadius(const vh::vec3i& chunk, int chunkRadius) const;      // .h:348
 
+    HashData& getHashData() { return m_sceneRepHashSDF->getHashData(); }               // .h:287
+    const HashParams& getHashParams() { return m_sceneRepHashSDF->getHashParams(); }   // .h:283
     const vh::vec3i& getMinGridPos() const { return m_minGridPos; }
     const vh::vec3i& getMaxGridPos() const { return m_maxGridPos; }
     const vh::vec3f& getVoxelExtends() const { return m_voxelExtents; }
@@ -318,6 +320,71 @@ private:
     volatile bool s_terminateThread;
 
     CUDASceneRepHashSDF* m_sceneRepHashSDF;
+};
+
+
+// ---------------------------------------------------------------------------
+// CUDAMarchingCubesHashSDF (DSC/CUDAMarchingCubesHashSDF.h:8-67, .cpp:16-224): iso-surface extraction of the
+// voxel hash into a triangle mesh, and the mesh file.
+typedef VhMarchingCubesParams MarchingCubesParams;
+typedef VhMarchingCubesData MarchingCubesData;
+
+namespace vh {
+// what the reference keeps in an mLib MeshDataf: vertices, per-vertex colours (r,g,b,1), index triples
+struct MeshData {
+    std::vector<vec3f> m_Vertices;
+    std::vector<float> m_Colors;                      // 4 per vertex
+    std::vector<unsigned int> m_FaceIndicesVertices;  // 3 per face; empty = triangle soup (face i = 3i, 3i+1, 3i+2)
+    void clear() { m_Vertices.clear(); m_Colors.clear(); m_FaceIndicesVertices.clear(); }
+    bool hasVertexIndices() const { return !m_FaceIndicesVertices.empty(); }
+    void makeTriangleSoupIndices();
+    // mLib MeshData::mergeCloseVertices(thresh, approx = true) / removeDuplicateFaces() / merge() / applyTransform():
+    // mLib is not part of the reference tree; these restate its documented behaviour ("parity unpinned")
+    void mergeCloseVertices(float thresh);
+    void removeDuplicateFaces();
+    void merge(const MeshData& other);
+    void applyTransform(const mat4f& t);
+    void saveToPLY(const std::string& filename) const; // binary little endian, x y z red green blue alpha + faces
+};
+} // namespace vh
+
+class CUDAMarchingCubesHashSDF {
+public:
+    explicit CUDAMarchingCubesHashSDF(const MarchingCubesParams& params, vhStream_t stream = nullptr);
+    ~CUDAMarchingCubesHashSDF();
+    CUDAMarchingCubesHashSDF(const CUDAMarchingCubesHashSDF&) = delete;
+    CUDAMarchingCubesHashSDF& operator=(const CUDAMarchingCubesHashSDF&) = delete;
+
+    // parametersFromGlobalAppState, .h:19-28: the four GlobalAppState values it reads, as arguments
+    static MarchingCubesParams parameters(unsigned int marchingCubesMaxNumTriangles, float SDFMarchingCubeThreshFactor,
+                                          float SDFVoxelSize, unsigned int hashNumBuckets);
+
+    void clearMeshBuffer() { m_meshData.clear(); }
+    // copies the result of the last extraction to the host and appends it to the mesh (.cpp:31-86); throws when the
+    // triangle buffer overflowed.  offlineProcessing (GlobalAppState::s_offlineProcessing): merge each batch first.
+    void copyTrianglesToCPU();
+    void setOfflineProcessing(bool on) { m_offline = on; }
+    void saveMesh(const std::string& filename, const vh::mat4f* transform = nullptr, bool overwriteExistingFile = false);
+
+    // per chunk of the grid: stream the chunk and its neighbours in, extract inside the chunk's box (.cpp:149-192)
+    void extractIsoSurface(CUDASceneRepChunkGrid& chunkGrid, const vh::vec3f& camPos, float radius);
+    void extractIsoSurface(const HashData& hashData, const HashParams& hashParams, const vh::vec3f& minCorner = { 0, 0, 0 },
+                           const vh::vec3f& maxCorner = { 0, 0, 0 }, bool boxEnabled = false);
+    void extractIsoSurfaceWithoutCopy(const HashData& hashData, const HashParams& hashParams, const vh::vec3f& minCorner = { 0, 0, 0 },
+                                      const vh::vec3f& maxCorner = { 0, 0, 0 }, bool boxEnabled = false);
+
+    const vh::MeshData& getMeshData() const { return m_meshData; }
+    const MarchingCubesData& getMarchingCubesData() const { return m_data; }
+    unsigned int getNumTriangles();       // of the last extraction (blocks); may exceed m_maxNumTriangles on overflow
+    unsigned int getNumOccupiedBlocks();  // of the last extraction
+    void downloadTriangles(VhTriangle* out, unsigned int n); // the device triangle buffer of the last extraction
+
+private:
+    MarchingCubesParams m_params;
+    MarchingCubesData m_data;
+    vh::MeshData m_meshData;
+    vhStream_t m_stream;
+    bool m_offline;
 };
 
 #endif // VH_HPP

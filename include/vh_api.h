@@ -246,6 +246,45 @@ int vh_chunk_grid_download_host_blocks(VhChunkGrid* g, VhSDFBlockDesc* descs, Vh
 int vh_chunk_grid_save_to_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
 int vh_chunk_grid_load_from_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
 
+/* ---- marching cubes -------------------------------------------------------------------------
+ * launcher level: resetMarchingCubesCUDA / extractIsoSurfacePass1CUDA / extractIsoSurfacePass2CUDA
+ * (DSC/CUDAMarchingCubesSDF.cu:29-40, 94-105, 132-143).  The reference passes a RayCastData only for its member
+ * function trilinearInterpolationSimpleFastFast; no buffer of it is read, so it is not a parameter here.
+ * d_numTriangles counts every triangle produced; those beyond m_maxNumTriangles are dropped (the reference clamps
+ * the counter instead). */
+int vh_marching_cubes_data_alloc(VhMarchingCubesData* data, const VhMarchingCubesParams* params); /* MarchingCubesData::allocate */
+void vh_marching_cubes_data_free(VhMarchingCubesData* data);
+int vh_marching_cubes_update_params(const VhMarchingCubesData* data, const VhMarchingCubesParams* params, vhStream_t stream);
+int vh_reset_marching_cubes(const VhMarchingCubesData* data, vhStream_t stream);
+int vh_extract_iso_surface_pass1(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesData* data, vhStream_t stream);
+int vh_extract_iso_surface_pass2(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesData* data,
+                                 uint32_t numOccupiedBlocks, vhStream_t stream);
+
+/* handle level: CUDAMarchingCubesHashSDF (DSC/CUDAMarchingCubesHashSDF.h:8-67) */
+typedef struct VhMarchingCubes VhMarchingCubes;
+int vh_marching_cubes_create(const VhMarchingCubesParams* params, vhStream_t stream, VhMarchingCubes** out);
+void vh_marching_cubes_destroy(VhMarchingCubes* mc);
+/* parametersFromGlobalAppState :19-28 */
+int vh_marching_cubes_parameters(uint32_t maxNumTriangles, float threshFactor, float voxelSize, uint32_t hashNumBuckets,
+                                 VhMarchingCubesParams* out);
+int vh_marching_cubes_set_offline_processing(VhMarchingCubes* mc, int enabled);
+/* extractIsoSurface(hashData, hashParams, rayCastData, minCorner, maxCorner, boxEnabled) .cpp:194-209 (copy = 1)
+ * / extractIsoSurfaceWithoutCopy :211-224 (copy = 0) */
+int vh_marching_cubes_extract_iso_surface(VhMarchingCubes* mc, const VhHashData* hd, const VhHashParams* hp,
+                                          const float minCorner[3], const float maxCorner[3], int boxEnabled, int copy);
+/* extractIsoSurface(chunkGrid, rayCastData, camPos, radius) .cpp:149-192 */
+int vh_marching_cubes_extract_iso_surface_chunk_grid(VhMarchingCubes* mc, VhChunkGrid* grid, const float camPos[3], float radius);
+int vh_marching_cubes_copy_triangles_to_cpu(VhMarchingCubes* mc);
+int vh_marching_cubes_clear_mesh_buffer(VhMarchingCubes* mc);
+/* counts of the last extraction: {triangles produced, occupied blocks} */
+int vh_marching_cubes_get_counts(VhMarchingCubes* mc, uint32_t out[2]);
+int vh_marching_cubes_download_triangles(VhMarchingCubes* mc, VhTriangle* out, uint32_t n);
+/* the host mesh (getMetaDataf): sizes {vertices, face indices (3 per face; 0 = triangle soup)}, then the arrays */
+int vh_marching_cubes_get_mesh_size(VhMarchingCubes* mc, uint64_t out[2]);
+int vh_marching_cubes_get_mesh(VhMarchingCubes* mc, float* vertices3, float* colors4, uint32_t* faceIndices);
+/* saveMesh(filename, transform, overwriteExistingFile) .cpp:89-145; transform may be NULL */
+int vh_marching_cubes_save_mesh(VhMarchingCubes* mc, const char* filename, const float transform[16], int overwriteExistingFile);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,40 @@ typedef struct VhSDFBlockDesc {
     int32_t ptr;
 } VhSDFBlockDesc;
 
+/* MarchingCubesParams, DSC/MarchingCubesSDFUtil.h:9-23 (64 B; the reference's leading `bool` is the low byte of
+ * m_boxEnabled, its padding the rest). */
+typedef struct VhMarchingCubesParams {
+    uint32_t m_boxEnabled;
+    float m_minCorner[3];
+    uint32_t m_maxNumTriangles;
+    float m_maxCorner[3];
+    uint32_t m_sdfBlockSize;
+    uint32_t m_hashNumBuckets;
+    uint32_t m_hashBucketSize;
+    float m_threshMarchingCubes;
+    float m_threshMarchingCubes2;
+    float dummy[3];
+} VhMarchingCubesParams;
+
+/* MarchingCubesData::Vertex / ::Triangle, DSC/MarchingCubesSDFUtil.h:33-44 (24 B / 72 B) */
+typedef struct VhVertex {
+    float p[3];
+    float c[3];
+} VhVertex;
+typedef struct VhTriangle {
+    VhVertex v0, v1, v2;
+} VhTriangle;
+
+/* MarchingCubesData, DSC/MarchingCubesSDFUtil.h:27-326 (device buffers) */
+typedef struct VhMarchingCubesData {
+    VhMarchingCubesParams* d_params;
+    uint32_t* d_numOccupiedBlocks;
+    uint32_t* d_occupiedBlocks; /* hash entry indices, Ne of them */
+    uint32_t* d_numTriangles;
+    VhTriangle* d_triangles;    /* m_maxNumTriangles */
+    uint8_t m_bIsOnGPU;
+} VhMarchingCubesData;
+
 /* The five GlobalAppState flags the reference host classes read
  * (DSC/CUDASceneRepHashSDF.h:249,251,329,331; DSC/CUDASceneRepChunkGrid.cpp:13). */
 typedef struct VhSceneOptions {

@@ -51,6 +51,8 @@ def lib():
     L.vho_stream_in_pass1.argtypes = [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_void_p]
     L.vho_stream_in_pass1.restype = C.c_uint32
     L.vho_stream_in_pass2.argtypes = [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.vho_extract_iso_surface.argtypes = [P(T.HashData), P(T.HashParams), P(T.MarchingCubesParams), C.c_void_p, C.c_uint32]
+    L.vho_extract_iso_surface.restype = C.c_uint32
     L.vho_alloc_block.argtypes = [P(T.HashData), P(T.HashParams), P(C.c_int32)]
     L.vho_delete_hash_entry_element.argtypes = [P(T.HashData), P(T.HashParams), P(C.c_int32)]
     L.vho_delete_hash_entry_element.restype = C.c_int
@@ -271,6 +273,13 @@ class OracleScene:
 
     def hash_table(self):
         return self.array("d_hash", T.HASH_ENTRY_DTYPE, self.num_entries())
+
+    def extract_iso_surface(self, mc_params, max_triangles=None):
+        """marching cubes over every allocated block -> triangles (T.TRIANGLE_DTYPE), in the reference's serial order"""
+        cap = int(max_triangles if max_triangles is not None else mc_params.m_maxNumTriangles)
+        out = np.zeros(cap, dtype=T.TRIANGLE_DTYPE)
+        n = self.L.vho_extract_iso_surface(C.byref(self.hd), C.byref(self.hp), C.byref(mc_params), out.ctypes.data, cap)
+        return out[:min(n, cap)], int(n)
 
     def compactified(self):
         return self.array("d_hashCompactified", T.HASH_ENTRY_DTYPE, self.hp.m_numOccupiedBlocks)

@@ -1165,3 +1165,131 @@ void vho_synth_frame(const double* spheres, int nSpheres, int inside, const floa
         }
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* marching cubes (DSC/MarchingCubesSDFUtil.h, DSC/CUDAMarchingCubesSDF.cu)  */
+/* ------------------------------------------------------------------------- */
+
+#include "../include/vh_mc_tables.h"
+
+/* vertexInterp, DSC/MarchingCubesSDFUtil.h:237-262 */
+static VhVertex mc_vertex_interp(float isolevel, f3 p1, f3 p2, float d1, float d2, const uint8_t c1[3], const uint8_t c2[3])
+{
+    VhVertex r1, r2, res;
+    r1.p[0] = p1.x; r1.p[1] = p1.y; r1.p[2] = p1.z;
+    r1.c[0] = (float)c1[0] / 255.f; r1.c[1] = (float)c1[1] / 255.f; r1.c[2] = (float)c1[2] / 255.f;
+    r2.p[0] = p2.x; r2.p[1] = p2.y; r2.p[2] = p2.z;
+    r2.c[0] = (float)c2[0] / 255.f; r2.c[1] = (float)c2[1] / 255.f; r2.c[2] = (float)c2[2] / 255.f;
+    if (fabsf(isolevel - d1) < 0.00001f) return r1;
+    if (fabsf(isolevel - d2) < 0.00001f) return r2;
+    if (fabsf(d1 - d2) < 0.00001f) return r1;
+    const float mu = (isolevel - d1) / (d2 - d1);
+    res.p[0] = p1.x + mu * (p2.x - p1.x);
+    res.p[1] = p1.y + mu * (p2.y - p1.y);
+    res.p[2] = p1.z + mu * (p2.z - p1.z);
+    res.c[0] = (float)((float)c1[0] + mu * (float)((int)c2[0] - (int)c1[0])) / 255.f;
+    res.c[1] = (float)((float)c1[1] + mu * (float)((int)c2[1] - (int)c1[1])) / 255.f;
+    res.c[2] = (float)((float)c1[2] + mu * (float)((int)c2[2] - (int)c1[2])) / 255.f;
+    return res;
+}
+
+/* extractIsoSurfaceAtPosition, DSC/MarchingCubesSDFUtil.h:154-235.  Returns the number of triangles written to t[5]. */
+static int mc_at_position(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesParams* mp, f3 worldPos, VhTriangle t[5])
+{
+    if ((mp->m_boxEnabled & 0xffu) == 1u) { /* isInBoxAA :264-271 */
+        if (worldPos.x < mp->m_minCorner[0] || worldPos.x > mp->m_maxCorner[0]) return 0;
+        if (worldPos.y < mp->m_minCorner[1] || worldPos.y > mp->m_maxCorner[1]) return 0;
+        if (worldPos.z < mp->m_minCorner[2] || worldPos.z > mp->m_maxCorner[2]) return 0;
+    }
+    const float isolevel = 0.0f;
+    const float P = hp->m_virtualVoxelSize / 2.0f;
+    const float M = -P;
+    /* corner order of the reference: 000,100,010,001,110,011,101,111 */
+    static const int cs[8][3] = { {0,0,0},{1,0,0},{0,1,0},{0,0,1},{1,1,0},{0,1,1},{1,0,1},{1,1,1} };
+    f3 p[8];
+    float d[8];
+    int valid[8];
+    uint8_t cdummy[3];
+    for (int k = 0; k < 8; k++) { /* the reference evaluates all eight before testing any */
+        p[k] = mk3(worldPos.x + (cs[k][0] ? P : M), worldPos.y + (cs[k][1] ? P : M), worldPos.z + (cs[k][2] ? P : M));
+        d[k] = 0.0f;
+        valid[k] = trilinear(hd, hp, p[k], &d[k], cdummy);
+    }
+    for (int k = 0; k < 8; k++) if (!valid[k]) return 0;
+    const f3 p000 = p[0], p100 = p[1], p010 = p[2], p001 = p[3], p110 = p[4], p011 = p[5], p101 = p[6], p111 = p[7];
+    const float dist000 = d[0], dist100 = d[1], dist010 = d[2], dist001 = d[3], dist110 = d[4], dist011 = d[5], dist101 = d[6], dist111 = d[7];
+
+    uint32_t cubeindex = 0;
+    if (dist010 < isolevel) cubeindex += 1;
+    if (dist110 < isolevel) cubeindex += 2;
+    if (dist100 < isolevel) cubeindex += 4;
+    if (dist000 < isolevel) cubeindex += 8;
+    if (dist011 < isolevel) cubeindex += 16;
+    if (dist111 < isolevel) cubeindex += 32;
+    if (dist101 < isolevel) cubeindex += 64;
+    if (dist001 < isolevel) cubeindex += 128;
+
+    const float thres = mp->m_threshMarchingCubes;
+    for (int k = 0; k < 8; k++)
+        for (int l = 0; l < 8; l++) {
+            if (d[k] * d[l] < 0.0f) {
+                if (fabsf(d[k]) + fabsf(d[l]) > thres) return 0;
+            } else {
+                if (fabsf(d[k] - d[l]) > thres) return 0;
+            }
+        }
+    for (int k = 0; k < 8; k++) if (fabsf(d[k]) > mp->m_threshMarchingCubes2) return 0;
+
+    const uint32_t edges = VH_MC_EDGE[cubeindex];
+    if (edges == 0 || edges == 255) return 0;
+
+    const VhVoxel v = get_voxel_world(hd, hp, worldPos);
+    VhVertex vl[12];
+    memset(vl, 0, sizeof(vl));
+    if (edges & 1)    vl[0]  = mc_vertex_interp(isolevel, p010, p110, dist010, dist110, v.color, v.color);
+    if (edges & 2)    vl[1]  = mc_vertex_interp(isolevel, p110, p100, dist110, dist100, v.color, v.color);
+    if (edges & 4)    vl[2]  = mc_vertex_interp(isolevel, p100, p000, dist100, dist000, v.color, v.color);
+    if (edges & 8)    vl[3]  = mc_vertex_interp(isolevel, p000, p010, dist000, dist010, v.color, v.color);
+    if (edges & 16)   vl[4]  = mc_vertex_interp(isolevel, p011, p111, dist011, dist111, v.color, v.color);
+    if (edges & 32)   vl[5]  = mc_vertex_interp(isolevel, p111, p101, dist111, dist101, v.color, v.color);
+    if (edges & 64)   vl[6]  = mc_vertex_interp(isolevel, p101, p001, dist101, dist001, v.color, v.color);
+    if (edges & 128)  vl[7]  = mc_vertex_interp(isolevel, p001, p011, dist001, dist011, v.color, v.color);
+    if (edges & 256)  vl[8]  = mc_vertex_interp(isolevel, p010, p011, dist010, dist011, v.color, v.color);
+    if (edges & 512)  vl[9]  = mc_vertex_interp(isolevel, p110, p111, dist110, dist111, v.color, v.color);
+    if (edges & 1024) vl[10] = mc_vertex_interp(isolevel, p100, p101, dist100, dist101, v.color, v.color);
+    if (edges & 2048) vl[11] = mc_vertex_interp(isolevel, p000, p001, dist000, dist001, v.color, v.color);
+
+    int n = 0;
+    unsigned long long tri = VH_MC_TRI[cubeindex];
+    while ((tri & 0xFull) != 0xFull) {
+        t[n].v0 = vl[tri & 0xF];
+        t[n].v1 = vl[(tri >> 4) & 0xF];
+        t[n].v2 = vl[(tri >> 8) & 0xF];
+        tri >>= 12;
+        n++;
+    }
+    return n;
+}
+
+uint32_t vho_extract_iso_surface(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesParams* mp,
+                                 VhTriangle* out, uint32_t maxTriangles)
+{
+    const uint32_t ne = hp->m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    uint32_t count = 0;
+    for (uint32_t idx = 0; idx < ne; idx++) {
+        const VhHashEntry* e = &hd->d_hash[idx];
+        if (e->ptr == VH_FREE_ENTRY) continue;
+        const i3 base = block_to_vvp(mki3(e->pos[0], e->pos[1], e->pos[2]));
+        for (int z = 0; z < VH_SDF_BLOCK_SIZE; z++)
+            for (int y = 0; y < VH_SDF_BLOCK_SIZE; y++)
+                for (int x = 0; x < VH_SDF_BLOCK_SIZE; x++) {
+                    VhTriangle t[5];
+                    const int n = mc_at_position(hd, hp, mp, vvp_to_world(hp, mki3(base.x + x, base.y + y, base.z + z)), t);
+                    for (int k = 0; k < n; k++) {
+                        if (count < maxTriangles) out[count] = t[k];
+                        count++;
+                    }
+                }
+    }
+    return count;
+}

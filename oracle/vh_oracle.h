@@ -89,6 +89,13 @@ void vho_raycast_render(const VhHashData* hd, const VhHashParams* hp, const VhRa
                         const VhDepthCameraParams* cp, VhRayCastParams* rp,
                         const float lastRigidTransform[16]);
 
+/* Marching cubes: extractIsoSurfacePass1Kernel + extractIsoSurfacePass2Kernel (DSC/CUDAMarchingCubesSDF.cu:65-121)
+ * with extractIsoSurfaceAtPosition / vertexInterp (DSC/MarchingCubesSDFUtil.h:154-262), serially: entries in table
+ * order, voxels of a block in thread order (x fastest).  Stores at most maxTriangles triangles and returns the
+ * number produced. */
+uint32_t vho_extract_iso_surface(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesParams* mp,
+                                 VhTriangle* out, uint32_t maxTriangles);
+
 /* Synthetic scenes of SURVEY.md section 8(d): analytic spheres, double
  * precision, rounded once to float.  spheres = n x {cx,cy,cz,r}; inside != 0
  * renders the far intersection (camera inside the sphere, scene S2). */

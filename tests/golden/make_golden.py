@@ -56,7 +56,41 @@ def run_case(name):
     return out
 
 
+def sorted_triangles(tris):
+    """canonical form of a triangle soup: the 72-byte records in byte order"""
+    v = np.ascontiguousarray(tris).view(np.dtype((np.void, T.TRIANGLE_DTYPE.itemsize))).ravel()
+    return np.ascontiguousarray(tris)[np.argsort(v, kind="stable")]
+
+
+MC_CASES = {
+    # name: (width, height, params, buckets, sdf blocks, scene, frames of a 100-frame orbit, thresh factor)
+    "mc_s1_64x48_p4": (64, 48, "P4", 1 << 12, 1 << 10, "S1", [0, 1, 2, 3], 10.0),
+}
+
+
+def run_mc_case(name):
+    W, H, ps, nb, nblk, scene, frames, tf = MC_CASES[name]
+    hp = T.make_hash_params(nb, nblk, **synth.PARAM_SETS[ps])
+    cp = T.make_depth_camera_params(W, H)
+    spheres, inside, radius = synth.scene(scene)
+    sc = O.OracleScene(hp, cp, None, T.make_scene_options(offline=True, gc=False))
+    for k in frames:
+        pose = synth.orbit_pose(k, 100, radius)
+        depth, color = O.synth_frame(spheres, inside, pose, cp)
+        sc.integrate(pose, depth, color)
+    mp = T.make_marching_cubes_params(hp, 1 << 18, tf)
+    tris, n = sc.extract_iso_surface(mp)
+    assert n == len(tris) and n > 100
+    return dict(width=W, height=H, params=ps, num_buckets=nb, num_sdf_blocks=nblk, scene=scene, frames=np.array(frames),
+                thresh_factor=tf, triangles=sorted_triangles(tris).view(np.float32).reshape(n, 18))
+
+
 def main():
+    for name in MC_CASES:
+        out = run_mc_case(name)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path), "bytes,", len(out["triangles"]), "triangles")
     for name in CASES:
         data = run_case(name)
         path = os.path.join(HERE, name + ".npz")

@@ -10,6 +10,7 @@
 
 struct VhSceneRep { CUDASceneRepHashSDF impl; VhSceneRep(const HashParams& p, const VhSceneOptions& o, vhStream_t s) : impl(p, o, s) {} };
 struct VhRayCast { CUDARayCastSDF impl; VhRayCast(const RayCastParams& p, vhStream_t s) : impl(p, s) {} };
+struct VhMarchingCubes { CUDAMarchingCubesHashSDF impl; VhMarchingCubes(const MarchingCubesParams& p, vhStream_t s) : impl(p, s) {} };
 struct VhChunkGrid {
     CUDASceneRepChunkGrid impl;
     VhChunkGrid(CUDASceneRepHashSDF* s, const vh::vec3f& e, const vh::vec3i& d, const vh::vec3i& m, unsigned int l, bool en, unsigned int parts)
@@ -286,6 +287,89 @@ int vh_chunk_grid_load_from_file(VhChunkGrid* g, const char* filename, const flo
 {
     if (!g || !filename || !camPos) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { g->impl.loadFromFile(filename, toVec(camPos), radius); });
+}
+
+// ---- CUDAMarchingCubesHashSDF ---------------------------------------------------
+
+int vh_marching_cubes_create(const VhMarchingCubesParams* params, vhStream_t stream, VhMarchingCubes** out)
+{
+    if (!params || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] { *out = new VhMarchingCubes(*params, stream); });
+}
+void vh_marching_cubes_destroy(VhMarchingCubes* mc) { delete mc; }
+int vh_marching_cubes_parameters(uint32_t maxNumTriangles, float threshFactor, float voxelSize, uint32_t hashNumBuckets,
+                                 VhMarchingCubesParams* out)
+{
+    if (!out) return VH_ERR_BAD_ARGUMENT;
+    *out = CUDAMarchingCubesHashSDF::parameters(maxNumTriangles, threshFactor, voxelSize, hashNumBuckets);
+    return VH_OK;
+}
+int vh_marching_cubes_set_offline_processing(VhMarchingCubes* mc, int enabled)
+{
+    if (!mc) return VH_ERR_BAD_ARGUMENT;
+    mc->impl.setOfflineProcessing(enabled != 0);
+    return VH_OK;
+}
+int vh_marching_cubes_extract_iso_surface(VhMarchingCubes* mc, const VhHashData* hd, const VhHashParams* hp,
+                                          const float minCorner[3], const float maxCorner[3], int boxEnabled, int copy)
+{
+    if (!mc || !hd || !hp) return VH_ERR_BAD_ARGUMENT;
+    const vh::vec3f lo = minCorner ? toVec(minCorner) : vh::vec3f{ 0, 0, 0 }, hi = maxCorner ? toVec(maxCorner) : vh::vec3f{ 0, 0, 0 };
+    return guarded([&] {
+        if (copy) mc->impl.extractIsoSurface(*hd, *hp, lo, hi, boxEnabled != 0);
+        else mc->impl.extractIsoSurfaceWithoutCopy(*hd, *hp, lo, hi, boxEnabled != 0);
+    });
+}
+int vh_marching_cubes_extract_iso_surface_chunk_grid(VhMarchingCubes* mc, VhChunkGrid* grid, const float camPos[3], float radius)
+{
+    if (!mc || !grid || !camPos) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { mc->impl.extractIsoSurface(grid->impl, toVec(camPos), radius); });
+}
+int vh_marching_cubes_copy_triangles_to_cpu(VhMarchingCubes* mc)
+{
+    if (!mc) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { mc->impl.copyTrianglesToCPU(); });
+}
+int vh_marching_cubes_clear_mesh_buffer(VhMarchingCubes* mc)
+{
+    if (!mc) return VH_ERR_BAD_ARGUMENT;
+    mc->impl.clearMeshBuffer();
+    return VH_OK;
+}
+int vh_marching_cubes_get_counts(VhMarchingCubes* mc, uint32_t out[2])
+{
+    if (!mc || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { out[0] = mc->impl.getNumTriangles(); out[1] = mc->impl.getNumOccupiedBlocks(); });
+}
+int vh_marching_cubes_download_triangles(VhMarchingCubes* mc, VhTriangle* out, uint32_t n)
+{
+    if (!mc) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { mc->impl.downloadTriangles(out, n); });
+}
+int vh_marching_cubes_get_mesh_size(VhMarchingCubes* mc, uint64_t out[2])
+{
+    if (!mc || !out) return VH_ERR_BAD_ARGUMENT;
+    out[0] = mc->impl.getMeshData().m_Vertices.size();
+    out[1] = mc->impl.getMeshData().m_FaceIndicesVertices.size();
+    return VH_OK;
+}
+int vh_marching_cubes_get_mesh(VhMarchingCubes* mc, float* vertices3, float* colors4, uint32_t* faceIndices)
+{
+    if (!mc) return VH_ERR_BAD_ARGUMENT;
+    const vh::MeshData& m = mc->impl.getMeshData();
+    if (vertices3 && !m.m_Vertices.empty()) std::memcpy(vertices3, m.m_Vertices.data(), sizeof(vh::vec3f) * m.m_Vertices.size());
+    if (colors4 && !m.m_Colors.empty()) std::memcpy(colors4, m.m_Colors.data(), sizeof(float) * m.m_Colors.size());
+    if (faceIndices && !m.m_FaceIndicesVertices.empty()) std::memcpy(faceIndices, m.m_FaceIndicesVertices.data(), sizeof(uint32_t) * m.m_FaceIndicesVertices.size());
+    return VH_OK;
+}
+int vh_marching_cubes_save_mesh(VhMarchingCubes* mc, const char* filename, const float transform[16], int overwriteExistingFile)
+{
+    if (!mc || !filename) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        if (transform) { const vh::mat4f t = toMat(transform); mc->impl.saveMesh(filename, &t, overwriteExistingFile != 0); }
+        else mc->impl.saveMesh(filename, nullptr, overwriteExistingFile != 0);
+    });
 }
 
 } // extern "C"

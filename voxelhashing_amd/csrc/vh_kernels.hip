@@ -426,21 +426,22 @@ VHD void divmod_small(uint32_t i, uint32_t nx, float rnx, uint32_t& q, uint32_t&
 // Cost of a tile in units of one empty-space step; a full sample (8 taps) weighs kCostSample of them.  The wave's
 // cost is its busiest lane's: k_render stores the tile's cost class for the next frame's launch order.
 constexpr uint32_t kCostSample = 6;
-constexpr uint32_t kCostClasses = 16;
-constexpr uint32_t kCostClassWidth = 16;
+constexpr uint32_t kCostClasses = 32;
+constexpr uint32_t kCostClassWidth = 8;
 
 // Launch order of the next k_render (one workgroup of k_interval_splat, beside the others): tiles sorted by the cost
 // class the previous k_render stored, dearest first, dealt to the workgroups (4 tiles each) in rows of numCUs that
 // alternate direction.  The hardware places workgroup g on compute unit g mod numCUs (all of them are resident), so
 // a compute unit receives one workgroup of every row: the dearest of one row with the cheapest of the next.
-__device__ void schedule_tiles(uint32_t* sched, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t* sCount /*[2 * 16 * kCostClasses]*/)
+__device__ void schedule_tiles(uint32_t* sched, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t* sCount /*[2 * 256]*/)
 {
     // layout: {phase the slots were made for, -, -, -}, cost class per tile, {tile, phase} per launch slot
     const uint32_t* cls = sched + 4;
     uint2* slots = reinterpret_cast<uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u));
     if (threadIdx.x == 0) sched[0] = phase;
     // counting sort with kSub sub-bins per class (keyed by the thread): 64 lanes adding to one LDS word serialise
-    constexpr uint32_t kSub = 16, kBins = kCostClasses * kSub;
+    constexpr uint32_t kSub = 8, kBins = kCostClasses * kSub;
+    static_assert(kBins == 4u * kWave, "the scan below gives four bins to each lane of one wave");
     for (uint32_t i = threadIdx.x; i < 2u * kBins; i += blockDim.x) sCount[i] = 0u;
     __syncthreads();
     const uint32_t sub = threadIdx.x % kSub;
@@ -1267,6 +1268,255 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
 }
 
 // ---------------------------------------------------------------------------
+// marching cubes (DSC/CUDAMarchingCubesSDF.cu:65-143, DSC/MarchingCubesSDFUtil.h:154-311)
+//
+// Pass 1 lists the allocated hash entries (from the occupancy bits, not by reading all Ne entries); pass 2 runs one
+// 512-thread workgroup per listed block, one voxel per thread.  A voxel's eight corner samples are trilinear
+// interpolations whose 64 taps all lie in the block and a one-voxel shell around it, so the workgroup first stages
+// that 10x10x10 neighbourhood (27 block look-ups, 8 KB) in LDS and every tap is an LDS read.  Tap coordinates and
+// weights are computed with the reference's arithmetic (they decide bits of the output); a tap outside the staged
+// shell -- it cannot happen for finite coordinates, but nothing here relies on that -- takes the global path.
+// Triangles are appended with one atomic per wave; their order in the buffer differs from the reference's (and is
+// not deterministic there either).
+// ---------------------------------------------------------------------------
+
+namespace mc_tables {
+#define VH_MC_QUAL __device__ const
+#include "../../include/vh_mc_tables.h"
+#undef VH_MC_QUAL
+} // namespace mc_tables
+
+__global__ void k_mc_reset(VhMarchingCubesData d)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { d.d_numTriangles[0] = 0u; d.d_numOccupiedBlocks[0] = 0u; }
+}
+
+// extractIsoSurfacePass1Kernel :65-92 (its box test is commented out in the reference)
+__global__ __launch_bounds__(256) void k_mc_pass1(VhHashData hd, VhHashParams hp, VhMarchingCubesData d)
+{
+    const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
+    const uint32_t wordIdx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bits = (wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
+    while (__any(bits != 0u)) {
+        const bool has = bits != 0u;
+        const uint32_t bucket = wordIdx * 32u + (has ? (uint32_t)(__ffs((int)bits) - 1) : 0u);
+        bits &= bits - 1u;
+        int ptrs[VH_HASH_BUCKET_SIZE];
+#pragma unroll
+        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) ptrs[j] = has ? hd.d_hash[(uint64_t)bucket * VH_HASH_BUCKET_SIZE + j].ptr : VH_FREE_ENTRY;
+#pragma unroll
+        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
+            const bool keep = ptrs[j] != VH_FREE_ENTRY;
+            const uint64_t m = __ballot(keep);
+            if (m) {
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                uint32_t base = 0;
+                if ((int)lane_id() == leader) base = atomicAdd(d.d_numOccupiedBlocks, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                if (keep) d.d_occupiedBlocks[base + (uint32_t)__popcll(m & lanemask_lt())] = bucket * VH_HASH_BUCKET_SIZE + j;
+            }
+        }
+    }
+}
+
+constexpr int kMcTile = VH_SDF_BLOCK_SIZE + 2; // block plus a one-voxel shell
+
+struct McTile {
+    const uint2* vox; // LDS, kMcTile^3
+    I3 base;          // voxel coordinates of tile cell (0,0,0) = block base - 1
+    const VhHashData& hd;
+    const VhHashParams& hp;
+    // getVoxel(float3) :390-400: the zero voxel where there is no block
+    VHD Vox voxel_at(F3 worldPos) const
+    {
+        const I3 v = world_to_vvp(hp.m_virtualVoxelSize, worldPos);
+        const int tx = v.x - base.x, ty = v.y - base.y, tz = v.z - base.z;
+        if ((unsigned)tx < (unsigned)kMcTile && (unsigned)ty < (unsigned)kMcTile && (unsigned)tz < (unsigned)kMcTile)
+            return unpack_vox(vox[(tz * kMcTile + ty) * kMcTile + tx]);
+        const int ptr = lookup_ptr(hd, hp, vvp_to_block(v));
+        if (ptr == VH_FREE_ENTRY) return unpack_vox(make_uint2(0u, 0u));
+        const VhVoxel* g = &hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(local1(v.z) * 64 + local1(v.y) * 8 + local1(v.x))];
+        return unpack_vox(*reinterpret_cast<const uint2*>(g));
+    }
+    // trilinearInterpolationSimpleFastFast, DSC/RayCastSDFUtil.h:97-116 (the colour it also forms is not used here)
+    VHD bool trilinear(F3 pos, float& dist) const
+    {
+        const float oSet = hp.m_virtualVoxelSize;
+        const F3 pd = mk3(pos.x - oSet / 2.0f, pos.y - oSet / 2.0f, pos.z - oSet / 2.0f);
+        const float fx = pos.x / oSet, fy = pos.y / oSet, fz = pos.z / oSet;
+        const float wx = fx - floorf(fx), wy = fy - floorf(fy), wz = fz - floorf(fz);
+        float d = 0.0f;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t combo = (0x75634210u >> (4u * k)) & 7u; // reference tap order 000,100,010,001,110,011,101,111
+            const bool bx = combo & 1u, by = combo & 2u, bz = combo & 4u;
+            const Vox v = voxel_at(mk3(bx ? pd.x + oSet : pd.x + 0.0f, by ? pd.y + oSet : pd.y + 0.0f, bz ? pd.z + oSet : pd.z + 0.0f));
+            if (v.weight() == 0u) return false;
+            const float s = (bx ? wx : 1.0f - wx) * (by ? wy : 1.0f - wy) * (bz ? wz : 1.0f - wz);
+            d += s * v.sdf;
+        }
+        dist = d;
+        return true;
+    }
+};
+
+// vertexInterp, DSC/MarchingCubesSDFUtil.h:237-262, with c1 == c2 == the voxel's colour as at every call site
+VHD VhVertex mc_vertex(F3 p1, F3 p2, float d1, float d2, uint32_t cw)
+{
+    const float isolevel = 0.0f;
+    const float cr = (float)(cw & 0xffu), cg = (float)((cw >> 8) & 0xffu), cb = (float)((cw >> 16) & 0xffu);
+    VhVertex r;
+    const bool first = fabsf(isolevel - d1) < 0.00001f, second = fabsf(isolevel - d2) < 0.00001f, flat = fabsf(d1 - d2) < 0.00001f;
+    if (first || second || flat) {
+        const F3 p = first ? p1 : (second ? p2 : p1);
+        r.p[0] = p.x; r.p[1] = p.y; r.p[2] = p.z;
+        r.c[0] = cr / 255.f; r.c[1] = cg / 255.f; r.c[2] = cb / 255.f;
+        return r;
+    }
+    const float mu = (isolevel - d1) / (d2 - d1);
+    r.p[0] = p1.x + mu * (p2.x - p1.x);
+    r.p[1] = p1.y + mu * (p2.y - p1.y);
+    r.p[2] = p1.z + mu * (p2.z - p1.z);
+    r.c[0] = (cr + mu * 0.0f) / 255.f; // (float)(c2 - c1) is 0
+    r.c[1] = (cg + mu * 0.0f) / 255.f;
+    r.c[2] = (cb + mu * 0.0f) / 255.f;
+    return r;
+}
+
+// extractIsoSurfacePass2Kernel :107-129 + extractIsoSurfaceAtPosition
+__global__ __launch_bounds__(512) void k_mc_pass2(VhHashData hd, VhHashParams hp, VhMarchingCubesData data, uint32_t numBlocks)
+{
+    __shared__ uint2 sVox[kMcTile * kMcTile * kMcTile];
+    __shared__ int sPtr[27];
+    const uint32_t t = threadIdx.x;
+    if (blockIdx.x >= numBlocks) return;
+    const uint32_t idx = data.d_occupiedBlocks[blockIdx.x];
+    const int4 q = load_quad(&hd.d_hash[idx]);
+    if (q.w == VH_FREE_ENTRY) return; // block-uniform
+    const I3 blk = mki3(q.x, q.y, q.z);
+    const I3 base = mki3(blk.x * VH_SDF_BLOCK_SIZE - 1, blk.y * VH_SDF_BLOCK_SIZE - 1, blk.z * VH_SDF_BLOCK_SIZE - 1);
+    if (t < 27u) {
+        const int dx = (int)(t % 3u) - 1, dy = (int)((t / 3u) % 3u) - 1, dz = (int)(t / 9u) - 1;
+        sPtr[t] = (dx == 0 && dy == 0 && dz == 0) ? q.w : lookup_ptr(hd, hp, mki3(blk.x + dx, blk.y + dy, blk.z + dz));
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < (uint32_t)(kMcTile * kMcTile * kMcTile); i += blockDim.x) {
+        const int tx = (int)(i % kMcTile), ty = (int)((i / kMcTile) % kMcTile), tz = (int)(i / (kMcTile * kMcTile));
+        // shell cells belong to the neighbour block on that side
+        const int nx = tx == 0 ? 0 : (tx == kMcTile - 1 ? 2 : 1), ny = ty == 0 ? 0 : (ty == kMcTile - 1 ? 2 : 1), nz = tz == 0 ? 0 : (tz == kMcTile - 1 ? 2 : 1);
+        const int ptr = sPtr[(nz * 3 + ny) * 3 + nx];
+        uint2 v = make_uint2(0u, 0u);
+        if (ptr != VH_FREE_ENTRY) {
+            const int lx = (tx + 7) & 7, ly = (ty + 7) & 7, lz = (tz + 7) & 7; // (t - 1) mod 8
+            v = *reinterpret_cast<const uint2*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]);
+        }
+        sVox[i] = v;
+    }
+    __syncthreads();
+
+    const VhMarchingCubesParams mp = *data.d_params;
+    const McTile tile{ sVox, base, hd, hp };
+    // threadIdx of the reference's 8x8x8 block: x fastest
+    const I3 pi = mki3(base.x + 1 + (int)(t & 7u), base.y + 1 + (int)((t >> 3) & 7u), base.z + 1 + (int)(t >> 6));
+    const F3 worldPos = vvp_to_world(hp.m_virtualVoxelSize, pi);
+
+    uint32_t nTri = 0;
+    uint64_t triList = ~0ull;
+    float dist[8]; // reference corner order 000,100,010,001,110,011,101,111
+    const float P = hp.m_virtualVoxelSize / 2.0f, M = -P;
+    bool ok = true;
+    if ((mp.m_boxEnabled & 0xffu) == 1u) { // isInBoxAA :264-271
+        if (worldPos.x < mp.m_minCorner[0] || worldPos.x > mp.m_maxCorner[0]) ok = false;
+        if (worldPos.y < mp.m_minCorner[1] || worldPos.y > mp.m_maxCorner[1]) ok = false;
+        if (worldPos.z < mp.m_minCorner[2] || worldPos.z > mp.m_maxCorner[2]) ok = false;
+    }
+    if (ok) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t combo = (0x75634210u >> (4u * k)) & 7u;
+            dist[k] = 0.0f;
+            const bool v = tile.trilinear(mk3(worldPos.x + ((combo & 1u) ? P : M), worldPos.y + ((combo & 2u) ? P : M), worldPos.z + ((combo & 4u) ? P : M)), dist[k]);
+            ok = ok && v;
+        }
+    }
+    uint32_t cubeindex = 0;
+    if (ok) {
+        const float isolevel = 0.0f;
+        if (dist[2] < isolevel) cubeindex += 1;   // 010
+        if (dist[4] < isolevel) cubeindex += 2;   // 110
+        if (dist[1] < isolevel) cubeindex += 4;   // 100
+        if (dist[0] < isolevel) cubeindex += 8;   // 000
+        if (dist[5] < isolevel) cubeindex += 16;  // 011
+        if (dist[7] < isolevel) cubeindex += 32;  // 111
+        if (dist[6] < isolevel) cubeindex += 64;  // 101
+        if (dist[3] < isolevel) cubeindex += 128; // 001
+        const float thres = mp.m_threshMarchingCubes;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++)
+#pragma unroll
+            for (uint32_t l = 0; l < 8u; l++) {
+                if (dist[k] * dist[l] < 0.0f) { if (fabsf(dist[k]) + fabsf(dist[l]) > thres) ok = false; }
+                else { if (fabsf(dist[k] - dist[l]) > thres) ok = false; }
+            }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) if (fabsf(dist[k]) > mp.m_threshMarchingCubes2) ok = false;
+        const uint32_t edges = mc_tables::VH_MC_EDGE[cubeindex];
+        if (edges == 0u || edges == 255u) ok = false;
+    }
+    if (ok) {
+        triList = mc_tables::VH_MC_TRI[cubeindex];
+        uint64_t l = triList;
+        while ((l & 0xFull) != 0xFull) { nTri++; l >>= 12; }
+    }
+
+    // one atomic per wave: exclusive scan of the lanes' triangle counts
+    const uint32_t lane = lane_id();
+    uint32_t incl = nTri;
+#pragma unroll
+    for (int off = 1; off < (int)kWave; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += up;
+    }
+    const uint32_t waveTotal = (uint32_t)__shfl((int)incl, (int)kWave - 1);
+    if (waveTotal == 0u) return; // wave-uniform
+    uint32_t waveBase = 0u;
+    if (lane == kWave - 1u) waveBase = atomicAdd(data.d_numTriangles, waveTotal);
+    waveBase = (uint32_t)__shfl((int)waveBase, (int)kWave - 1);
+    uint32_t at = waveBase + incl - nTri;
+    if (nTri == 0u) return;
+
+    const Vox own = tile.voxel_at(worldPos);
+    // Bourke's edges in the reference's corner names (vertlist, :205-216): endpoints as x|y<<1|z<<2, three bits each
+    constexpr uint64_t kEdgeA = 0ull | (2ull << 0) | (3ull << 3) | (1ull << 6) | (0ull << 9) | (6ull << 12) | (7ull << 15) | (5ull << 18) | (4ull << 21) | (2ull << 24) | (3ull << 27) | (1ull << 30) | (0ull << 33);
+    constexpr uint64_t kEdgeB = 0ull | (3ull << 0) | (1ull << 3) | (0ull << 6) | (2ull << 9) | (7ull << 12) | (5ull << 15) | (4ull << 18) | (6ull << 21) | (6ull << 24) | (7ull << 27) | (5ull << 30) | (4ull << 33);
+    // corner bits x|y<<1|z<<2  ->  index in the reference's sample order 000,100,010,001,110,011,101,111
+    constexpr uint32_t kOrder = 0u | (1u << 4) | (2u << 8) | (4u << 12) | (3u << 16) | (6u << 20) | (5u << 24) | (7u << 28);
+    auto corner_dist = [&](uint32_t c) {
+        const uint32_t k = (kOrder >> (4u * c)) & 7u;
+        float r = dist[0];
+#pragma unroll
+        for (uint32_t j = 1; j < 8u; j++) r = (k == j) ? dist[j] : r;
+        return r;
+    };
+    auto corner_pos = [&](uint32_t c) {
+        return mk3(worldPos.x + ((c & 1u) ? P : M), worldPos.y + ((c & 2u) ? P : M), worldPos.z + ((c & 4u) ? P : M));
+    };
+    auto edge_vertex = [&](uint32_t e) {
+        const uint32_t a = (uint32_t)(kEdgeA >> (3u * e)) & 7u, b = (uint32_t)(kEdgeB >> (3u * e)) & 7u;
+        return mc_vertex(corner_pos(a), corner_pos(b), corner_dist(a), corner_dist(b), own.cw);
+    };
+#pragma unroll 1
+    for (uint64_t l = triList; (l & 0xFull) != 0xFull; l >>= 12, at++) {
+        if (at >= mp.m_maxNumTriangles) break; // appendTriangle :283-309 drops what does not fit; the host sees the full count
+        VhTriangle tri;
+        tri.v0 = edge_vertex((uint32_t)(l & 0xFull));
+        tri.v1 = edge_vertex((uint32_t)((l >> 4) & 0xFull));
+        tri.v2 = edge_vertex((uint32_t)((l >> 8) & 0xFull));
+        data.d_triangles[at] = tri;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // streaming (DSC/CUDASceneRepChunkGrid.cu)
 // ---------------------------------------------------------------------------
 
@@ -1638,6 +1888,30 @@ int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, 
     if (width * height == 0) return VH_OK;
     k_compute_normals<<<cdiv((uint64_t)width * height, 256), 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height);
+    return vh_last_launch_error();
+}
+
+int vh_reset_marching_cubes(const VhMarchingCubesData* data, vhStream_t stream)
+{
+    if (!data || !data->d_numTriangles || !data->d_numOccupiedBlocks) return VH_ERR_BAD_ARGUMENT;
+    k_mc_reset<<<1, 64, 0, (hipStream_t)stream>>>(*data);
+    return vh_last_launch_error();
+}
+
+int vh_extract_iso_surface_pass1(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesData* data, vhStream_t stream)
+{
+    if (!hd || !hp || !data || !data->d_occupiedBlocks) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
+    k_mc_pass1<<<cdiv(nWords, 256), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *data);
+    return vh_last_launch_error();
+}
+
+int vh_extract_iso_surface_pass2(const VhHashData* hd, const VhHashParams* hp, const VhMarchingCubesData* data,
+                                 uint32_t numOccupiedBlocks, vhStream_t stream)
+{
+    if (!hd || !hp || !data || !data->d_params || !data->d_triangles) return VH_ERR_BAD_ARGUMENT;
+    if (numOccupiedBlocks == 0) return VH_OK;
+    k_mc_pass2<<<numOccupiedBlocks, 512, 0, (hipStream_t)stream>>>(*hd, *hp, *data, numOccupiedBlocks);
     return vh_last_launch_error();
 }
 

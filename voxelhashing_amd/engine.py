@@ -445,3 +445,72 @@ class LauncherScene:
         snap = canonical.snapshot(d["hash"], d.get("sdf_blocks"), d["heap"], d["heap_counter"], self.hp, with_voxels)
         snap.update(compactified=d["compactified"], decisions=d["decisions"], raw=d)
         return snap
+
+
+class CUDAMarchingCubesHashSDF:
+    """Mirror of DSC/CUDAMarchingCubesHashSDF.h:8-67 over the C ABI."""
+
+    def __init__(self, params, stream=None):
+        self.L = load()
+        self._params = params
+        self.stream = stream
+        h = C.c_void_p()
+        check(self.L.vh_marching_cubes_create(C.byref(params), stream, C.byref(h)), "vh_marching_cubes_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_marching_cubes_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setOfflineProcessing(self, on):
+        check(self.L.vh_marching_cubes_set_offline_processing(self.handle, 1 if on else 0), "setOfflineProcessing")
+
+    def extractIsoSurface(self, hashData, hashParams, minCorner=(0, 0, 0), maxCorner=(0, 0, 0), boxEnabled=False, copy=True):
+        check(self.L.vh_marching_cubes_extract_iso_surface(self.handle, C.byref(hashData), C.byref(hashParams), f16(minCorner),
+                                                           f16(maxCorner), int(boxEnabled), int(copy)), "extractIsoSurface")
+
+    def extractIsoSurfaceWithoutCopy(self, hashData, hashParams, minCorner=(0, 0, 0), maxCorner=(0, 0, 0), boxEnabled=False):
+        self.extractIsoSurface(hashData, hashParams, minCorner, maxCorner, boxEnabled, copy=False)
+
+    def extractIsoSurfaceChunkGrid(self, chunkGrid, camPos, radius):
+        check(self.L.vh_marching_cubes_extract_iso_surface_chunk_grid(self.handle, chunkGrid.handle, f16(camPos), radius),
+              "extractIsoSurface(chunkGrid)")
+
+    def copyTrianglesToCPU(self):
+        check(self.L.vh_marching_cubes_copy_triangles_to_cpu(self.handle), "copyTrianglesToCPU")
+
+    def clearMeshBuffer(self):
+        check(self.L.vh_marching_cubes_clear_mesh_buffer(self.handle), "clearMeshBuffer")
+
+    def counts(self):
+        out = (C.c_uint32 * 2)()
+        check(self.L.vh_marching_cubes_get_counts(self.handle, out), "get_counts")
+        return dict(triangles=int(out[0]), occupied_blocks=int(out[1]))
+
+    def triangles(self):
+        """device triangle buffer of the last extraction -> numpy array of T.TRIANGLE_DTYPE"""
+        n = min(self.counts()["triangles"], self._params.m_maxNumTriangles)
+        out = np.zeros(n, dtype=T.TRIANGLE_DTYPE)
+        if n:
+            check(self.L.vh_marching_cubes_download_triangles(self.handle, out.ctypes.data, n), "download_triangles")
+        return out
+
+    def mesh(self):
+        sz = (C.c_uint64 * 2)()
+        check(self.L.vh_marching_cubes_get_mesh_size(self.handle, sz), "get_mesh_size")
+        v = np.zeros((int(sz[0]), 3), dtype=np.float32)
+        c = np.zeros((int(sz[0]), 4), dtype=np.float32)
+        f = np.zeros(int(sz[1]), dtype=np.uint32)
+        check(self.L.vh_marching_cubes_get_mesh(self.handle, v.ctypes.data, c.ctypes.data, f.ctypes.data), "get_mesh")
+        return dict(vertices=v, colors=c, faces=f.reshape(-1, 3))
+
+    def saveMesh(self, filename, transform=None, overwriteExistingFile=False):
+        t = f16(transform) if transform is not None else None
+        check(self.L.vh_marching_cubes_save_mesh(self.handle, filename.encode(), t, int(overwriteExistingFile)), "saveMesh")

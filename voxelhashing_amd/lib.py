@@ -77,6 +77,25 @@ PROTOTYPES = {
     "vh_raycast_set_timing": (C.c_int, [_VP, C.c_int]),
     "vh_raycast_set_timing_stride": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "vh_raycast_set_interval_splatting": (C.c_int, [_VP, C.c_int]),
+    "vh_marching_cubes_data_alloc": (C.c_int, [P(T.MarchingCubesData), P(T.MarchingCubesParams)]),
+    "vh_marching_cubes_data_free": (None, [P(T.MarchingCubesData)]),
+    "vh_marching_cubes_update_params": (C.c_int, [P(T.MarchingCubesData), P(T.MarchingCubesParams), _VP]),
+    "vh_reset_marching_cubes": (C.c_int, [P(T.MarchingCubesData), _VP]),
+    "vh_extract_iso_surface_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.MarchingCubesData), _VP]),
+    "vh_extract_iso_surface_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.MarchingCubesData), C.c_uint32, _VP]),
+    "vh_marching_cubes_create": (C.c_int, [P(T.MarchingCubesParams), _VP, P(_VP)]),
+    "vh_marching_cubes_destroy": (None, [_VP]),
+    "vh_marching_cubes_parameters": (C.c_int, [C.c_uint32, C.c_float, C.c_float, C.c_uint32, P(T.MarchingCubesParams)]),
+    "vh_marching_cubes_set_offline_processing": (C.c_int, [_VP, C.c_int]),
+    "vh_marching_cubes_extract_iso_surface": (C.c_int, [_VP, P(T.HashData), P(T.HashParams), P(C.c_float), P(C.c_float), C.c_int, C.c_int]),
+    "vh_marching_cubes_extract_iso_surface_chunk_grid": (C.c_int, [_VP, _VP, P(C.c_float), C.c_float]),
+    "vh_marching_cubes_copy_triangles_to_cpu": (C.c_int, [_VP]),
+    "vh_marching_cubes_clear_mesh_buffer": (C.c_int, [_VP]),
+    "vh_marching_cubes_get_counts": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_marching_cubes_download_triangles": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "vh_marching_cubes_get_mesh_size": (C.c_int, [_VP, P(C.c_uint64)]),
+    "vh_marching_cubes_get_mesh": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "vh_marching_cubes_save_mesh": (C.c_int, [_VP, C.c_char_p, P(C.c_float), C.c_int]),
     "vh_chunk_grid_create": (C.c_int, [_VP, _F16, P(C.c_int32), P(C.c_int32), C.c_uint32, C.c_int, C.c_uint32, P(_VP)]),
     "vh_chunk_grid_destroy": (None, [_VP]),
     "vh_chunk_grid_stream_out_to_cpu_pass0_gpu": (C.c_int, [_VP, _F16, C.c_float, C.c_int, C.c_int]),

@@ -110,6 +110,26 @@ class SDFBlockDesc(C.Structure):
     _fields_ = [("pos", C.c_int32 * 3), ("ptr", C.c_int32)]
 
 
+class MarchingCubesParams(C.Structure):
+    _fields_ = [
+        ("m_boxEnabled", C.c_uint32), ("m_minCorner", C.c_float * 3),
+        ("m_maxNumTriangles", C.c_uint32), ("m_maxCorner", C.c_float * 3),
+        ("m_sdfBlockSize", C.c_uint32), ("m_hashNumBuckets", C.c_uint32), ("m_hashBucketSize", C.c_uint32),
+        ("m_threshMarchingCubes", C.c_float), ("m_threshMarchingCubes2", C.c_float), ("dummy", C.c_float * 3),
+    ]
+
+
+class MarchingCubesData(C.Structure):
+    _fields_ = [
+        ("d_params", C.c_void_p), ("d_numOccupiedBlocks", C.c_void_p), ("d_occupiedBlocks", C.c_void_p),
+        ("d_numTriangles", C.c_void_p), ("d_triangles", C.c_void_p), ("m_bIsOnGPU", C.c_uint8),
+    ]
+
+
+# MarchingCubesData::Triangle = 3 x {float3 p, float3 c} (72 B)
+TRIANGLE_DTYPE = np.dtype([("v", [("p", np.float32, 3), ("c", np.float32, 3)], 3)])
+
+
 class SceneOptions(C.Structure):
     _fields_ = [
         ("s_offlineProcessing", C.c_uint8),
@@ -209,6 +229,19 @@ def make_raycast_params(hash_params, cam_params, ray_increment_factor=0.8, thres
     p.m_thresSampleDist = float(np.float32(thres_sample_dist_factor) * inc)
     p.m_thresDist = float(np.float32(thres_dist_factor) * inc)
     p.m_useGradients = 1 if use_gradients else 0
+    return p
+
+
+def make_marching_cubes_params(hash_params, max_num_triangles=1 << 20, thresh_factor=10.0):
+    """parametersFromGlobalAppState, DSC/CUDAMarchingCubesHashSDF.h:19-28 (s_SDFMarchingCubeThreshFactor = 10 in
+    the reference's zParameters files)"""
+    p = MarchingCubesParams()
+    p.m_maxNumTriangles = max_num_triangles
+    p.m_threshMarchingCubes = np.float32(thresh_factor) * np.float32(hash_params.m_virtualVoxelSize)
+    p.m_threshMarchingCubes2 = np.float32(thresh_factor) * np.float32(hash_params.m_virtualVoxelSize)
+    p.m_sdfBlockSize = 8
+    p.m_hashBucketSize = 10
+    p.m_hashNumBuckets = hash_params.m_hashNumBuckets
     return p
 
 
