@@ -1286,6 +1286,34 @@ namespace mc_tables {
 #undef VH_MC_QUAL
 } // namespace mc_tables
 
+// getHashEntryForSDFBlockPos :424-468 with the ten slots of the bucket in flight together (lookup_ptr walks them one
+// trip at a time, which is what a block that is NOT there costs whenever its bucket holds something else)
+VHD int lookup_ptr_wide(const VhHashData& hd, const VhHashParams& hp, I3 blk)
+{
+    const uint32_t ne = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    const uint32_t h = hash_pos(hp.m_hashNumBuckets, blk);
+    if (!bucket_maybe_occupied(hd, h)) return VH_FREE_ENTRY;
+    const uint32_t base = h * VH_HASH_BUCKET_SIZE, idxLast = base + VH_HASH_BUCKET_SIZE - 1;
+    int4 qs[VH_HASH_BUCKET_SIZE];
+#pragma unroll
+    for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) qs[j] = load_quad(&hd.d_hash[base + j]);
+    uint32_t off = hd.d_hash[idxLast].offset;
+#pragma unroll
+    for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++)
+        if (quad_matches(qs[j], blk)) return qs[j].w;
+    uint32_t maxIter = 0;
+#pragma unroll 1
+    while (maxIter < hp.m_hashMaxCollisionLinkedListSize) { // the list behind the last slot
+        if (off == 0) break;
+        const uint32_t i = (idxLast + off) % ne;
+        const int4 q = load_quad(&hd.d_hash[i]);
+        if (quad_matches(q, blk)) return q.w;
+        off = hd.d_hash[i].offset;
+        maxIter++;
+    }
+    return VH_FREE_ENTRY;
+}
+
 __global__ void k_mc_reset(VhMarchingCubesData d)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) { d.d_numTriangles[0] = 0u; d.d_numOccupiedBlocks[0] = 0u; }
@@ -1397,7 +1425,7 @@ __global__ __launch_bounds__(512) void k_mc_pass2(VhHashData hd, VhHashParams hp
     const I3 base = mki3(blk.x * VH_SDF_BLOCK_SIZE - 1, blk.y * VH_SDF_BLOCK_SIZE - 1, blk.z * VH_SDF_BLOCK_SIZE - 1);
     if (t < 27u) {
         const int dx = (int)(t % 3u) - 1, dy = (int)((t / 3u) % 3u) - 1, dz = (int)(t / 9u) - 1;
-        sPtr[t] = (dx == 0 && dy == 0 && dz == 0) ? q.w : lookup_ptr(hd, hp, mki3(blk.x + dx, blk.y + dy, blk.z + dz));
+        sPtr[t] = (dx == 0 && dy == 0 && dz == 0) ? q.w : lookup_ptr_wide(hd, hp, mki3(blk.x + dx, blk.y + dy, blk.z + dz));
     }
     __syncthreads();
     for (uint32_t i = t; i < (uint32_t)(kMcTile * kMcTile * kMcTile); i += blockDim.x) {
@@ -1422,7 +1450,7 @@ __global__ __launch_bounds__(512) void k_mc_pass2(VhHashData hd, VhHashParams hp
 
     uint32_t nTri = 0;
     uint64_t triList = ~0ull;
-    float dist[8]; // reference corner order 000,100,010,001,110,011,101,111
+    float dist[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }; // reference corner order 000,100,010,001,110,011,101,111
     const float P = hp.m_virtualVoxelSize / 2.0f, M = -P;
     bool ok = true;
     if ((mp.m_boxEnabled & 0xffu) == 1u) { // isInBoxAA :264-271
@@ -1430,14 +1458,22 @@ __global__ __launch_bounds__(512) void k_mc_pass2(VhHashData hd, VhHashParams hp
         if (worldPos.y < mp.m_minCorner[1] || worldPos.y > mp.m_maxCorner[1]) ok = false;
         if (worldPos.z < mp.m_minCorner[2] || worldPos.z > mp.m_maxCorner[2]) ok = false;
     }
-    if (ok) {
+    // The voxel itself is a tap of each of its eight corner samples (they lie half a voxel away, so their taps are
+    // the voxel and its neighbours) whenever the coordinates are far from the float -> int cliffs: an unobserved
+    // voxel (weight 0) then fails all eight, and most voxels of an allocated block are unobserved.
+    const bool tame = abs(pi.x) < (1 << 20) && abs(pi.y) < (1 << 20) && abs(pi.z) < (1 << 20);
+    if (ok && tame && (sVox[((int)(t >> 6) + 1) * kMcTile * kMcTile + ((int)((t >> 3) & 7u) + 1) * kMcTile + (int)(t & 7u) + 1].y >> 24) == 0u) ok = false;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 8u; k++) {
+        if (!__any(ok)) break; // wave-uniform: nothing left to sample in this 8x8 slab of voxels
+        const uint32_t combo = (0x75634210u >> (4u * k)) & 7u;
+        float dk = 0.0f;
+        bool v = false;
+        if (ok) v = tile.trilinear(mk3(worldPos.x + ((combo & 1u) ? P : M), worldPos.y + ((combo & 2u) ? P : M), worldPos.z + ((combo & 4u) ? P : M)), dk);
+        ok = ok && v;
+        // dist[k] with a run-time k would put the array in scratch
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) {
-            const uint32_t combo = (0x75634210u >> (4u * k)) & 7u;
-            dist[k] = 0.0f;
-            const bool v = tile.trilinear(mk3(worldPos.x + ((combo & 1u) ? P : M), worldPos.y + ((combo & 2u) ? P : M), worldPos.z + ((combo & 4u) ? P : M)), dist[k]);
-            ok = ok && v;
-        }
+        for (uint32_t j = 0; j < 8u; j++) dist[j] = (j == k) ? dk : dist[j];
     }
     uint32_t cubeindex = 0;
     if (ok) {
@@ -1451,10 +1487,11 @@ __global__ __launch_bounds__(512) void k_mc_pass2(VhHashData hd, VhHashParams hp
         if (dist[6] < isolevel) cubeindex += 64;  // 101
         if (dist[3] < isolevel) cubeindex += 128; // 001
         const float thres = mp.m_threshMarchingCubes;
+        // the reference tests all 64 ordered pairs; the test is symmetric and a value passes against itself
 #pragma unroll
         for (uint32_t k = 0; k < 8u; k++)
 #pragma unroll
-            for (uint32_t l = 0; l < 8u; l++) {
+            for (uint32_t l = k + 1u; l < 8u; l++) {
                 if (dist[k] * dist[l] < 0.0f) { if (fabsf(dist[k]) + fabsf(dist[l]) > thres) ok = false; }
                 else { if (fabsf(dist[k] - dist[l]) > thres) ok = false; }
             }
