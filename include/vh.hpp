@@ -338,8 +338,8 @@ struct MeshData {
     void clear() { m_Vertices.clear(); m_Colors.clear(); m_FaceIndicesVertices.clear(); }
     bool hasVertexIndices() const { return !m_FaceIndicesVertices.empty(); }
     void makeTriangleSoupIndices();
-    // mLib MeshData::mergeCloseVertices(thresh, approx = true) / removeDuplicateFaces() / merge() / applyTransform():
-    // mLib is not part of the reference tree; these restate its documented behaviour ("parity unpinned")
+    // MeshData::mergeCloseVertices(thresh, approx = true) / removeDuplicateFaces() / merge() / applyTransform() of the
+    // mLib revision the reference vendors (DepthSensingCUDA/Include/mLib/include/core-mesh/meshData.{h,cpp})
     void mergeCloseVertices(float thresh);
     void removeDuplicateFaces();
     void merge(const MeshData& other);

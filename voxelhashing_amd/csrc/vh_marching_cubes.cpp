@@ -2,9 +2,9 @@
 // (DSC/CUDAMarchingCubesHashSDF.{h,cpp}), MarchingCubesData::allocate/free/copyToCPU
 // (DSC/MarchingCubesSDFUtil.h:57-147) and the mesh container the reference takes from mLib (MeshDataf, MeshIOf).
 //
-// mLib is an external dependency of the reference and not part of its tree: mergeCloseVertices(thresh, approx),
-// removeDuplicateFaces() and the PLY writer restate mLib's published behaviour (core-mesh/meshData.cpp,
-// core-mesh/meshIO.cpp of niessner/mLib) and are "parity unpinned" -- no reference output pins them here.
+// The mesh functions restate the mLib revision the reference vendors (DepthSensingCUDA/Include/mLib/include/
+// core-mesh/meshData.{h,cpp}, meshIO.cpp, cited as MLIB/ below).  No reference output exists for them, so they are
+// pinned by that source only ("parity unpinned" as far as outputs go).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,7 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
-#include <map>
+#include <unordered_map>
 #include <set>
 
 #include "../../include/vh.hpp"
@@ -86,84 +86,128 @@ void vh::MeshData::makeTriangleSoupIndices()
     for (size_t i = 0; i < m_FaceIndicesVertices.size(); i++) m_FaceIndicesVertices[i] = (unsigned int)i;
 }
 
-// mLib mergeCloseVertices(thresh, approx = true): vertices are bucketed on a grid of cell size thresh and every
-// vertex of a cell is replaced by the first one that fell into it; unreferenced vertices are dropped.
+namespace {
+struct CellKey {
+    int x, y, z;
+    bool operator==(const CellKey& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct CellHash {
+    size_t operator()(const CellKey& k) const
+    {
+        return ((size_t)(unsigned int)k.x * 73856093u) ^ ((size_t)(unsigned int)k.y * 19349669u) ^ ((size_t)(unsigned int)k.z * 83492791u);
+    }
+};
+inline int signf(float v) { return (0.0f < v) - (v < 0.0f); }
+} // namespace
+
+// MLIB/core-mesh/meshData.cpp:216-289 with approx = true (the only mode the reference calls): a vertex goes to the
+// cell int(v / thresh + 0.5 sign(v)) (meshData.h:732-734); the 27 cells around it are searched in x-major order and
+// the first one that holds a vertex wins (meshData.cpp:197-212, no distance test); otherwise the vertex founds its
+// cell.  Faces are re-indexed and those left with a repeated index are dropped (removeDegeneratedFaces :293-318).
 void vh::MeshData::mergeCloseVertices(float thresh)
 {
-    if (thresh <= 0.0f || m_Vertices.empty()) return;
-    if (!hasVertexIndices()) makeTriangleSoupIndices();
-    std::map<std::array<long long, 3>, unsigned int> cell;
-    std::vector<unsigned int> remap(m_Vertices.size());
+    if (thresh <= 0.0f) throw vh::Error(VH_ERR_BAD_ARGUMENT, "mergeCloseVertices: invalid thresh");
+    if (m_Vertices.empty()) return;
+    std::unordered_map<CellKey, unsigned int, CellHash> grid;
+    grid.reserve(2 * m_Vertices.size());
+    std::vector<unsigned int> lookUp(m_Vertices.size());
     std::vector<vec3f> verts;
     std::vector<float> cols;
+    verts.reserve(m_Vertices.size());
     const bool hasColors = m_Colors.size() == 4 * m_Vertices.size();
-    for (size_t i = 0; i < m_Vertices.size(); i++) {
-        const vec3f& v = m_Vertices[i];
-        const std::array<long long, 3> key = { (long long)std::llround((double)v.x / thresh), (long long)std::llround((double)v.y / thresh),
-                                               (long long)std::llround((double)v.z / thresh) };
-        auto it = cell.find(key);
-        if (it == cell.end()) {
-            it = cell.emplace(key, (unsigned int)verts.size()).first;
-            verts.push_back(v);
-            if (hasColors) cols.insert(cols.end(), m_Colors.begin() + 4 * i, m_Colors.begin() + 4 * i + 4);
+    unsigned int cnt = 0;
+    for (size_t v = 0; v < m_Vertices.size(); v++) {
+        const vec3f& p = m_Vertices[v];
+        const CellKey c = { (int)(p.x / thresh + 0.5f * (float)signf(p.x)), (int)(p.y / thresh + 0.5f * (float)signf(p.y)),
+                            (int)(p.z / thresh + 0.5f * (float)signf(p.z)) };
+        unsigned int nn = (unsigned int)-1;
+        for (int i = -1; i <= 1 && nn == (unsigned int)-1; i++)
+            for (int j = -1; j <= 1 && nn == (unsigned int)-1; j++)
+                for (int k = -1; k <= 1 && nn == (unsigned int)-1; k++) {
+                    auto it = grid.find(CellKey{ c.x + i, c.y + j, c.z + k });
+                    if (it != grid.end()) nn = it->second;
+                }
+        if (nn == (unsigned int)-1) {
+            grid[c] = cnt;
+            verts.push_back(p);
+            if (hasColors) cols.insert(cols.end(), m_Colors.begin() + 4 * v, m_Colors.begin() + 4 * v + 4);
+            lookUp[v] = cnt++;
+        } else {
+            lookUp[v] = nn;
         }
-        remap[i] = it->second;
     }
-    for (auto& f : m_FaceIndicesVertices) f = remap[f];
-    m_Vertices.swap(verts);
-    if (hasColors) m_Colors.swap(cols);
-}
-
-// mLib removeDuplicateFaces(): faces over the same vertex set are kept once; faces that collapsed (two equal
-// indices after merging) are dropped
-void vh::MeshData::removeDuplicateFaces()
-{
-    std::set<std::array<unsigned int, 3>> seen;
+    for (auto& f : m_FaceIndicesVertices) f = lookUp[f];
+    if (verts.size() != m_Vertices.size()) {
+        m_Vertices.swap(verts);
+        if (hasColors) m_Colors.swap(cols);
+    }
     std::vector<unsigned int> faces;
+    faces.reserve(m_FaceIndicesVertices.size());
     for (size_t f = 0; f + 2 < m_FaceIndicesVertices.size(); f += 3) {
         const unsigned int a = m_FaceIndicesVertices[f], b = m_FaceIndicesVertices[f + 1], c = m_FaceIndicesVertices[f + 2];
         if (a == b || b == c || a == c) continue;
-        std::array<unsigned int, 3> key = { a, b, c };
-        std::sort(key.begin(), key.end());
-        if (!seen.insert(key).second) continue;
         faces.push_back(a); faces.push_back(b); faces.push_back(c);
     }
     m_FaceIndicesVertices.swap(faces);
 }
 
+// MLIB/core-mesh/meshData.cpp:36-105: of the faces over one vertex set the first is kept, in its own winding
+void vh::MeshData::removeDuplicateFaces()
+{
+    std::set<std::array<unsigned int, 3>> seen;
+    std::vector<unsigned int> faces;
+    faces.reserve(m_FaceIndicesVertices.size());
+    for (size_t f = 0; f + 2 < m_FaceIndicesVertices.size(); f += 3) {
+        std::array<unsigned int, 3> key = { m_FaceIndicesVertices[f], m_FaceIndicesVertices[f + 1], m_FaceIndicesVertices[f + 2] };
+        std::sort(key.begin(), key.end());
+        if (!seen.insert(key).second) continue;
+        faces.push_back(m_FaceIndicesVertices[f]); faces.push_back(m_FaceIndicesVertices[f + 1]); faces.push_back(m_FaceIndicesVertices[f + 2]);
+    }
+    m_FaceIndicesVertices.swap(faces);
+}
+
+// MLIB/core-mesh/meshData.cpp:473-556.  The vendored revision returns without doing anything when *this is empty
+// (the assignment is commented out, :479-482), which would leave the reference's offline path with an empty mesh
+// for ever; here an empty mesh takes the other one over (fenced reference defects).
 void vh::MeshData::merge(const MeshData& other)
 {
     if (other.m_Vertices.empty()) return;
-    if (!hasVertexIndices() && !m_Vertices.empty()) makeTriangleSoupIndices();
+    if (m_Vertices.empty()) { *this = other; return; }
+    if (hasVertexIndices() != other.hasVertexIndices()) throw vh::Error(VH_ERR_BAD_ARGUMENT, "invalid mesh conversion");
     const unsigned int base = (unsigned int)m_Vertices.size();
     m_Vertices.insert(m_Vertices.end(), other.m_Vertices.begin(), other.m_Vertices.end());
     m_Colors.insert(m_Colors.end(), other.m_Colors.begin(), other.m_Colors.end());
-    if (other.hasVertexIndices()) {
-        for (unsigned int f : other.m_FaceIndicesVertices) m_FaceIndicesVertices.push_back(base + f);
-    } else {
-        for (unsigned int i = 0; i < (unsigned int)(other.m_Vertices.size() / 3 * 3); i++) m_FaceIndicesVertices.push_back(base + i);
+    for (unsigned int f : other.m_FaceIndicesVertices) m_FaceIndicesVertices.push_back(base + f);
+}
+
+// MLIB/core-mesh/meshData.h:471-479 with Matrix4x4 * point3d = implicit w = 1 and de-homogenisation
+// (MLIB/core-math/matrix4x4.h:459-468)
+void vh::MeshData::applyTransform(const mat4f& t)
+{
+    for (auto& v : m_Vertices) {
+        const float x = t.m[0] * v.x + t.m[1] * v.y + t.m[2] * v.z + t.m[3];
+        const float y = t.m[4] * v.x + t.m[5] * v.y + t.m[6] * v.z + t.m[7];
+        const float z = t.m[8] * v.x + t.m[9] * v.y + t.m[10] * v.z + t.m[11];
+        const float w = t.m[12] * v.x + t.m[13] * v.y + t.m[14] * v.z + t.m[15];
+        v = { x / w, y / w, z / w };
     }
 }
 
-void vh::MeshData::applyTransform(const mat4f& t)
-{
-    for (auto& v : m_Vertices) v = t.transformPoint(v);
-}
-
+// MeshIO::saveToPLY, MLIB/core-mesh/meshIO.cpp:485-556
 void vh::MeshData::saveToPLY(const std::string& filename) const
 {
     std::ofstream f(filename, std::ios::binary);
     if (!f) throw vh::Error(VH_ERR_IO, "cannot write " + filename);
     const bool hasColors = m_Colors.size() == 4 * m_Vertices.size();
     const size_t nFaces = hasVertexIndices() ? m_FaceIndicesVertices.size() / 3 : m_Vertices.size() / 3;
-    f << "ply\nformat binary_little_endian 1.0\nelement vertex " << m_Vertices.size() << "\nproperty float x\nproperty float y\nproperty float z\n";
+    f << "ply\nformat binary_little_endian 1.0\ncomment MLIB generated\nelement vertex " << m_Vertices.size() << "\nproperty float x\nproperty float y\nproperty float z\n";
     if (hasColors) f << "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty uchar alpha\n";
     f << "element face " << nFaces << "\nproperty list uchar int vertex_indices\nend_header\n";
     for (size_t i = 0; i < m_Vertices.size(); i++) {
         f.write((const char*)&m_Vertices[i], 12);
         if (hasColors) {
             unsigned char c[4];
-            for (int k = 0; k < 4; k++) c[k] = (unsigned char)std::min(255.0f, std::max(0.0f, m_Colors[4 * i + k] * 255.0f));
+            for (int k = 0; k < 4; k++) c[k] = (unsigned char)(int)std::min(255.0f, std::max(0.0f, m_Colors[4 * i + k] * 255)); // vec4uc(c * 255)
             f.write((const char*)c, 4);
         }
     }
@@ -272,7 +316,7 @@ void CUDAMarchingCubesHashSDF::copyTrianglesToCPU()
     }
     if (!m_offline) {
         // triangle soup appended as it is
-        if (m_meshData.hasVertexIndices()) m_meshData.merge(md);
+        if (m_meshData.hasVertexIndices()) { md.makeTriangleSoupIndices(); m_meshData.merge(md); }
         else {
             m_meshData.m_Vertices.insert(m_meshData.m_Vertices.end(), md.m_Vertices.begin(), md.m_Vertices.end());
             m_meshData.m_Colors.insert(m_meshData.m_Colors.end(), md.m_Colors.begin(), md.m_Colors.end());
