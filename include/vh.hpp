@@ -387,4 +387,53 @@ private:
     bool m_offline;
 };
 
+
+// ---------------------------------------------------------------------------
+// CUDARGBDSensor over CUDARGBDAdapter (DSC/CUDARGBDSensor.{h,cpp}, DSC/CUDARGBDAdapter.{h,cpp}): the image path from
+// a sensor frame (float depth in metres + RGBX bytes, host memory, as RGBDSensor::getDepthFloat / getColorRGBX
+// deliver them) to the DepthCameraData that integrate() consumes, plus the camera-space and normal maps tracking uses.
+class CUDARGBDSensor {
+public:
+    struct Config {
+        unsigned int depthWidth, depthHeight, colorWidth, colorHeight; // sensor images
+        unsigned int adapterWidth, adapterHeight;                      // s_adapterWidth / s_adapterHeight: working resolution
+        float fx, fy, mx, my;                                          // depth intrinsics at sensor resolution
+        float sensorDepthMin, sensorDepthMax;                          // s_sensorDepthMin / s_sensorDepthMax
+        bool filterDepth; float sigmaD, sigmaR;                        // s_depthFilter, s_depthSigmaD, s_depthSigmaR
+        bool filterIntensity; float sigmaDIntensity, sigmaRIntensity;  // s_colorFilter, s_colorSigmaD, s_colorSigmaR
+    };
+    explicit CUDARGBDSensor(const Config& config, vhStream_t stream = nullptr);
+    ~CUDARGBDSensor();
+    CUDARGBDSensor(const CUDARGBDSensor&) = delete;
+    CUDARGBDSensor& operator=(const CUDARGBDSensor&) = delete;
+
+    void process(const float* h_depthFloat, const unsigned char* h_colorRGBX); // CUDARGBDSensor::process :147 (blocks until done)
+    void setFiterDepthValues(bool b = true, float sigmaD = 1.0f, float sigmaR = 1.0f);     // (sic) .h:37
+    void setFiterIntensityValues(bool b = true, float sigmaD = 1.0f, float sigmaR = 1.0f); // (sic) .h:40
+
+    const DepthCameraData& getDepthCameraData() const { return m_depthCameraData; }       // .h:78
+    const DepthCameraParams& getDepthCameraParams() const { return m_depthCameraParams; } // .h:82
+    float* getCameraSpacePositionsFloat4() { return d_cameraSpaceFloat4; }                // .h:50
+    float* getNormalMapFloat4() { return d_normalMapFloat4; }                             // .h:53
+    float* getDepthMapColorSpaceFloat() { return d_depthData; }                           // .h:44
+    float* getColorMapFilteredFloat4() { return d_colorData; }                            // .h:47
+    float* getIntensityMapFilteredFloat() { return d_intensityMapFilteredFloat; }
+    unsigned int getDepthWidth() const { return m_cfg.adapterWidth; }
+    unsigned int getDepthHeight() const { return m_cfg.adapterHeight; }
+    unsigned int getFrameNumber() const { return m_frameNumber; }
+
+private:
+    Config m_cfg;
+    vhStream_t m_stream;
+    unsigned int m_frameNumber;
+    bool m_bFilterDepthValues, m_bFilterIntensityValues;
+    float m_fBilateralFilterSigmaD, m_fBilateralFilterSigmaR, m_fBilateralFilterSigmaDIntensity, m_fBilateralFilterSigmaRIntensity;
+    DepthCameraParams m_depthCameraParams;
+    DepthCameraData m_depthCameraData;
+    float *d_depthMapFloat, *d_depthMapResampledFloat, *d_depthMapFilteredFloat, *d_intensityMapFilteredFloat;
+    unsigned char* d_colorMapRaw;
+    float *d_colorMapFloat4, *d_colorMapResampledFloat4, *d_cameraSpaceFloat4, *d_normalMapFloat4;
+    float *d_depthData, *d_colorData; // what m_depthCameraData points to
+};
+
 #endif // VH_HPP

@@ -246,6 +246,40 @@ int vh_chunk_grid_download_host_blocks(VhChunkGrid* g, VhSDFBlockDesc* descs, Vh
 int vh_chunk_grid_save_to_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
 int vh_chunk_grid_load_from_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
 
+/* ---- sensor pre-processing: the image kernels of DSC/CameraUtil.cu that CUDARGBDAdapter::process
+ * (DSC/CUDARGBDAdapter.cpp:93-137) and CUDARGBDSensor::process (DSC/CUDARGBDSensor.cpp:147-257) run on every frame.
+ * Device pointers; float4 maps are passed as float* (4 per pixel); MINF marks an invalid pixel.  The filters read
+ * their whole neighbourhood, so they do not work in place. */
+int vh_convert_color_raw_to_float4(float* d_output4, const uint8_t* d_inputRGBX, uint32_t width, uint32_t height, vhStream_t stream); /* :154 */
+int vh_resample_float_map(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const float* d_input,
+                          uint32_t inputWidth, uint32_t inputHeight, vhStream_t stream);                                       /* :1120 */
+int vh_resample_float4_map(float* d_output4, uint32_t outputWidth, uint32_t outputHeight, const float* d_input4,
+                           uint32_t inputWidth, uint32_t inputHeight, vhStream_t stream);                                      /* :1188 */
+int vh_copy_float_map(float* d_output, const float* d_input, uint32_t width, uint32_t height, vhStream_t stream);              /* :37  */
+int vh_copy_float4_map(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream);           /* :120 */
+int vh_set_invalid_float_map(float* d_output, uint32_t width, uint32_t height, vhStream_t stream);                             /* :348 */
+int vh_convert_color_to_intensity_float(float* d_output, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream); /* :269 */
+int vh_convert_depth_float_to_camera_space_float4(float* d_output4, const float* d_input, const VhDepthCameraParams* cp,
+                                                  uint32_t width, uint32_t height, vhStream_t stream);                         /* :409 */
+int vh_gauss_filter_float_map(float* d_output, const float* d_input, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream);    /* :595 */
+int vh_gauss_filter_float4_map(float* d_output4, const float* d_input4, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream); /* :653 */
+int vh_bilateral_filter_float_map(float* d_output, const float* d_input, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream); /* :485 */
+int vh_erode_depth_map(float* d_output, const float* d_input, int32_t structureSize, uint32_t width, uint32_t height, float dThresh,
+                       float fracReq, vhStream_t stream);                                                                       /* :1672 */
+
+/* handle level: CUDARGBDSensor over CUDARGBDAdapter (include/vh.hpp).  config = {depthW, depthH, colorW, colorH, adapterW,
+ * adapterH} and {fx, fy, mx, my, sensorDepthMin, sensorDepthMax}. */
+typedef struct VhRGBDSensor VhRGBDSensor;
+int vh_rgbd_sensor_create(const uint32_t sizes[6], const float intrinsics[6], vhStream_t stream, VhRGBDSensor** out);
+void vh_rgbd_sensor_destroy(VhRGBDSensor* s);
+int vh_rgbd_sensor_set_filter_depth_values(VhRGBDSensor* s, int enabled, float sigmaD, float sigmaR);
+int vh_rgbd_sensor_set_filter_intensity_values(VhRGBDSensor* s, int enabled, float sigmaD, float sigmaR);
+int vh_rgbd_sensor_process(VhRGBDSensor* s, const float* h_depthFloat, const uint8_t* h_colorRGBX);
+int vh_rgbd_sensor_get_depth_camera_data(VhRGBDSensor* s, VhDepthCameraData* out);
+int vh_rgbd_sensor_get_depth_camera_params(VhRGBDSensor* s, VhDepthCameraParams* out);
+/* device maps at adapter resolution: {camera space float4, normals float4, intensity float} */
+int vh_rgbd_sensor_get_maps(VhRGBDSensor* s, float** d_cameraSpace4, float** d_normals4, float** d_intensity);
+
 /* ---- marching cubes -------------------------------------------------------------------------
  * launcher level: resetMarchingCubesCUDA / extractIsoSurfacePass1CUDA / extractIsoSurfacePass2CUDA
  * (DSC/CUDAMarchingCubesSDF.cu:29-40, 94-105, 132-143).  The reference passes a RayCastData only for its member

@@ -51,6 +51,17 @@ def lib():
     L.vho_stream_in_pass1.argtypes = [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_void_p]
     L.vho_stream_in_pass1.restype = C.c_uint32
     L.vho_stream_in_pass2.argtypes = [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    for _n, _a in (('vho_convert_color_raw_to_float4', [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+                   ('vho_resample_float_map', [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
+                   ('vho_resample_float4_map', [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
+                   ('vho_convert_color_to_intensity_float', [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+                   ('vho_convert_depth_float_to_camera_space_float4', [C.c_void_p, C.c_void_p, P(T.DepthCameraParams), C.c_uint32, C.c_uint32]),
+                   ('vho_gauss_filter_float_map', [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32]),
+                   ('vho_gauss_filter_float4_map', [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32]),
+                   ('vho_bilateral_filter_float_map', [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32]),
+                   ('vho_erode_depth_map', [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_float, C.c_float])):
+        getattr(L, _n).argtypes = _a
+        getattr(L, _n).restype = None
     L.vho_extract_iso_surface.argtypes = [P(T.HashData), P(T.HashParams), P(T.MarchingCubesParams), C.c_void_p, C.c_uint32]
     L.vho_extract_iso_surface.restype = C.c_uint32
     L.vho_alloc_block.argtypes = [P(T.HashData), P(T.HashParams), P(C.c_int32)]
@@ -298,3 +309,36 @@ class OracleScene:
         from voxelhashing_amd import canonical
         return canonical.snapshot(self.hash_table(), self.sdf_blocks(), self.heap(),
                                   int(self.array("d_heapCounter", np.uint32, 1)[0]), self.hp)
+
+
+# ---- sensor pre-processing (DSC/CameraUtil.cu) ----
+
+def image_op(name, src, width, height, *args, out_channels=1, out_size=None, prefill=None):
+    """oracle twin of voxelhashing_amd.engine.image_op"""
+    L = lib()
+    src = np.ascontiguousarray(src)
+    ow, oh = out_size if out_size else (width, height)
+    out = np.zeros(ow * oh * out_channels, dtype=np.float32)
+    if prefill is not None:
+        out[:] = np.ascontiguousarray(prefill, dtype=np.float32).ravel()
+    fn = getattr(L, "vho_" + name)
+    if name in ("resample_float_map", "resample_float4_map"):
+        fn(out.ctypes.data, ow, oh, src.ctypes.data, width, height)
+    elif name == "convert_depth_float_to_camera_space_float4":
+        fn(out.ctypes.data, src.ctypes.data, C.byref(args[0]), width, height)
+    elif name == "erode_depth_map":
+        fn(out.ctypes.data, src.ctypes.data, int(args[0]), width, height, float(args[1]), float(args[2]))
+    elif name in ("gauss_filter_float_map", "gauss_filter_float4_map", "bilateral_filter_float_map"):
+        fn(out.ctypes.data, src.ctypes.data, float(args[0]), float(args[1]), width, height)
+    else:
+        fn(out.ctypes.data, src.ctypes.data, width, height)
+    return out.reshape((oh, ow, out_channels)) if out_channels > 1 else out.reshape((oh, ow))
+
+
+def compute_normals(camera_space4):
+    L = lib()
+    H, W = camera_space4.shape[:2]
+    src = np.ascontiguousarray(camera_space4, dtype=np.float32)
+    out = np.zeros_like(src)
+    L.vho_compute_normals(out.ctypes.data, src.ctypes.data, W, H)
+    return out

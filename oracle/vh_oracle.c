@@ -1293,3 +1293,201 @@ uint32_t vho_extract_iso_surface(const VhHashData* hd, const VhHashParams* hp, c
     }
     return count;
 }
+
+/* ------------------------------------------------------------------------- */
+/* sensor pre-processing (DSC/CameraUtil.cu)                                 */
+/* ------------------------------------------------------------------------- */
+
+/* convertColorRawToFloatDevice :137-152 */
+void vho_convert_color_raw_to_float4(float* out4, const uint8_t* in, uint32_t width, uint32_t height)
+{
+    for (uint32_t i = 0; i < width * height; i++) {
+        const uint8_t r = in[4 * i + 0], g = in[4 * i + 1], b = in[4 * i + 2], w = in[4 * i + 3];
+        if (r == 0 && g == 0 && b == 0) {
+            out4[4 * i + 0] = out4[4 * i + 1] = out4[4 * i + 2] = out4[4 * i + 3] = MINF;
+        } else {
+            out4[4 * i + 0] = r / 255.0f; out4[4 * i + 1] = g / 255.0f; out4[4 * i + 2] = b / 255.0f; out4[4 * i + 3] = (float)(w / 255);
+        }
+    }
+}
+
+/* bilinearInterpolationFloat :1071-1098; the int < unsigned comparisons of the reference reject negative coordinates */
+static float bilinear_float(float x, float y, const float* in, uint32_t W, uint32_t H)
+{
+    const int px = (int)floorf(x), py = (int)floorf(y);
+    const float alpha = x - (float)px, beta = y - (float)py;
+    float s0 = 0.0f, w0 = 0.0f, s1 = 0.0f, w1 = 0.0f;
+    if ((uint32_t)px < W && (uint32_t)py < H) { float v = in[(uint32_t)py * W + (uint32_t)px]; if (v != MINF) { s0 += (1.0f - alpha) * v; w0 += (1.0f - alpha); } }
+    if ((uint32_t)(px + 1) < W && (uint32_t)py < H) { float v = in[(uint32_t)py * W + (uint32_t)(px + 1)]; if (v != MINF) { s0 += alpha * v; w0 += alpha; } }
+    if ((uint32_t)px < W && (uint32_t)(py + 1) < H) { float v = in[(uint32_t)(py + 1) * W + (uint32_t)px]; if (v != MINF) { s1 += (1.0f - alpha) * v; w1 += (1.0f - alpha); } }
+    if ((uint32_t)(px + 1) < W && (uint32_t)(py + 1) < H) { float v = in[(uint32_t)(py + 1) * W + (uint32_t)(px + 1)]; if (v != MINF) { s1 += alpha * v; w1 += alpha; } }
+    const float p0 = s0 / w0, p1 = s1 / w1;
+    float ss = 0.0f, ww = 0.0f;
+    if (w0 > 0.0f) { ss += (1.0f - beta) * p0; ww += (1.0f - beta); }
+    if (w1 > 0.0f) { ss += beta * p1; ww += beta; }
+    return ww > 0.0f ? ss / ww : MINF;
+}
+
+/* resampleFloatMapDevice :1100-1118 */
+void vho_resample_float_map(float* out, uint32_t outW, uint32_t outH, const float* in, uint32_t inW, uint32_t inH)
+{
+    const float scaleWidth = (float)(inW - 1) / (float)(outW - 1), scaleHeight = (float)(inH - 1) / (float)(outH - 1);
+    for (uint32_t y = 0; y < outH; y++)
+        for (uint32_t x = 0; x < outW; x++) {
+            const uint32_t xInput = (uint32_t)((float)(int)x * scaleWidth + 0.5f), yInput = (uint32_t)((float)(int)y * scaleHeight + 0.5f);
+            if (xInput < inW && yInput < inH) out[y * outW + x] = bilinear_float((float)(int)x * scaleWidth, (float)(int)y * scaleHeight, in, inW, inH);
+        }
+}
+
+/* bilinearInterpolationFloat4 :1136-1166 */
+static void bilinear_float4(float x, float y, const float* in4, uint32_t W, uint32_t H, float out[4])
+{
+    const int px = (int)floorf(x), py = (int)floorf(y);
+    const float alpha = x - (float)px, beta = y - (float)py;
+    float s0[4] = { 0, 0, 0, 0 }, s1[4] = { 0, 0, 0, 0 }, w0 = 0.0f, w1 = 0.0f;
+    const int tx[4] = { px, px + 1, px, px + 1 }, ty[4] = { py, py, py + 1, py + 1 };
+    const float wg[4] = { 1.0f - alpha, alpha, 1.0f - alpha, alpha };
+    for (int k = 0; k < 4; k++) {
+        if ((uint32_t)tx[k] < W && (uint32_t)ty[k] < H) {
+            const float* v = &in4[4 * ((size_t)(uint32_t)ty[k] * W + (uint32_t)tx[k])];
+            if (v[0] != MINF && v[1] != MINF && v[2] != MINF) {
+                float* s = k < 2 ? s0 : s1;
+                for (int c = 0; c < 4; c++) s[c] += wg[k] * v[c];
+                if (k < 2) w0 += wg[k]; else w1 += wg[k];
+            }
+        }
+    }
+    float ss[4] = { 0, 0, 0, 0 }, ww = 0.0f;
+    if (w0 > 0.0f) { for (int c = 0; c < 4; c++) ss[c] += (1.0f - beta) * (s0[c] / w0); ww += (1.0f - beta); }
+    if (w1 > 0.0f) { for (int c = 0; c < 4; c++) ss[c] += beta * (s1[c] / w1); ww += beta; }
+    for (int c = 0; c < 4; c++) out[c] = ww > 0.0f ? ss[c] / ww : MINF;
+}
+
+/* resampleFloat4MapDevice :1168-1186 */
+void vho_resample_float4_map(float* out4, uint32_t outW, uint32_t outH, const float* in4, uint32_t inW, uint32_t inH)
+{
+    const float scaleWidth = (float)(inW - 1) / (float)(outW - 1), scaleHeight = (float)(inH - 1) / (float)(outH - 1);
+    for (uint32_t y = 0; y < outH; y++)
+        for (uint32_t x = 0; x < outW; x++) {
+            const uint32_t xInput = (uint32_t)((float)(int)x * scaleWidth + 0.5f), yInput = (uint32_t)((float)(int)y * scaleHeight + 0.5f);
+            if (xInput < inW && yInput < inH) bilinear_float4((float)(int)x * scaleWidth, (float)(int)y * scaleHeight, in4, inW, inH, &out4[4 * ((size_t)y * outW + x)]);
+        }
+}
+
+/* convertColorToIntensityFloatDevice :258-267 */
+void vho_convert_color_to_intensity_float(float* out, const float* in4, uint32_t width, uint32_t height)
+{
+    for (uint32_t i = 0; i < width * height; i++) out[i] = 0.299f * in4[4 * i] + 0.587f * in4[4 * i + 1] + 0.114f * in4[4 * i + 2];
+}
+
+/* convertDepthFloatToCameraSpaceFloat4Device :390-407 */
+void vho_convert_depth_float_to_camera_space_float4(float* out4, const float* in, const VhDepthCameraParams* cp, uint32_t width, uint32_t height)
+{
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            float* o = &out4[4 * ((size_t)y * width + x)];
+            const float depth = in[y * width + x];
+            o[0] = o[1] = o[2] = o[3] = MINF;
+            if (depth != MINF) {
+                const f3 p = depth_to_skeleton(cp, x, y, depth);
+                o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = 1.0f;
+            }
+        }
+}
+
+static inline float gauss_d(float sigma, int x, int y) { return expf(-((float)(x * x + y * y) / (2.0f * sigma * sigma))); } /* :436-439 */
+static inline double gauss_r(float sigma, float dist) { return exp(-(double)(dist * dist) / (2.0 * (double)sigma * (double)sigma)); } /* :426-429 */
+
+/* gaussFilterFloatMapDevice :555-593 */
+void vho_gauss_filter_float_map(float* out, const float* in, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
+{
+    const int kernelRadius = (int)ceil(2.0 * (double)sigmaD);
+    for (int y = 0; y < (int)H; y++)
+        for (int x = 0; x < (int)W; x++) {
+            float sum = 0.0f, sumWeight = 0.0f;
+            const float center = in[y * (int)W + x];
+            if (center != MINF)
+                for (int m = x - kernelRadius; m <= x + kernelRadius; m++)
+                    for (int n = y - kernelRadius; n <= y + kernelRadius; n++)
+                        if (m >= 0 && n >= 0 && m < (int)W && n < (int)H) {
+                            const float cur = in[n * (int)W + m];
+                            if (cur != MINF && fabsf(center - cur) < sigmaR) {
+                                const float weight = gauss_d(sigmaD, m - x, n - y);
+                                sumWeight += weight;
+                                sum += weight * cur;
+                            }
+                        }
+            out[y * (int)W + x] = sumWeight > 0.0f ? sum / sumWeight : MINF;
+        }
+}
+
+/* gaussFilterFloat4MapDevice :611-651 */
+void vho_gauss_filter_float4_map(float* out4, const float* in4, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
+{
+    const int kernelRadius = (int)ceil(2.0 * (double)sigmaD);
+    for (int y = 0; y < (int)H; y++)
+        for (int x = 0; x < (int)W; x++) {
+            float sum[4] = { 0, 0, 0, 0 }, sumWeight = 0.0f;
+            const float* center = &in4[4 * ((size_t)y * W + x)];
+            if (center[0] != MINF)
+                for (int m = x - kernelRadius; m <= x + kernelRadius; m++)
+                    for (int n = y - kernelRadius; n <= y + kernelRadius; n++)
+                        if (m >= 0 && n >= 0 && m < (int)W && n < (int)H) {
+                            const float* cur = &in4[4 * ((size_t)n * W + m)];
+                            if (cur[0] != MINF) {
+                                const float dx = center[0] - cur[0], dy = center[1] - cur[1], dz = center[2] - cur[2], dw = center[3] - cur[3];
+                                if (sqrtf(dx * dx + dy * dy + dz * dz + dw * dw) < sigmaR) {
+                                    const float weight = gauss_d(sigmaD, m - x, n - y);
+                                    sumWeight += weight;
+                                    for (int c = 0; c < 4; c++) sum[c] += weight * cur[c];
+                                }
+                            }
+                        }
+            float* o = &out4[4 * ((size_t)y * W + x)];
+            for (int c = 0; c < 4; c++) o[c] = sumWeight > 0.0f ? sum[c] / sumWeight : MINF;
+        }
+}
+
+/* bilateralFilterFloatMapDevice :446-483 */
+void vho_bilateral_filter_float_map(float* out, const float* in, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
+{
+    const int kernelRadius = (int)ceil(2.0 * (double)sigmaD);
+    for (int y = 0; y < (int)H; y++)
+        for (int x = 0; x < (int)W; x++) {
+            float sum = 0.0f, sumWeight = 0.0f, o = MINF;
+            const float center = in[y * (int)W + x];
+            if (center != MINF) {
+                for (int m = x - kernelRadius; m <= x + kernelRadius; m++)
+                    for (int n = y - kernelRadius; n <= y + kernelRadius; n++)
+                        if (m >= 0 && n >= 0 && m < (int)W && n < (int)H) {
+                            const float cur = in[n * (int)W + m];
+                            if (cur != MINF) {
+                                const float weight = (float)((double)gauss_d(sigmaD, m - x, n - y) * gauss_r(sigmaR, cur - center));
+                                sumWeight += weight;
+                                sum += weight * cur;
+                            }
+                        }
+                if (sumWeight > 0.0f) o = sum / sumWeight;
+            }
+            out[y * (int)W + x] = o;
+        }
+}
+
+/* erodeDepthMapDevice :1632-1670 */
+void vho_erode_depth_map(float* out, const float* in, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq)
+{
+    const int W = (int)width, H = (int)height;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            unsigned int count = 0;
+            const float oldDepth = in[y * W + x];
+            for (int i = -structureSize; i <= structureSize; i++)
+                for (int j = -structureSize; j <= structureSize; j++)
+                    if (x + j >= 0 && x + j < W && y + i >= 0 && y + i < H) {
+                        const float depth = in[(y + i) * W + (x + j)];
+                        if (depth == MINF || depth == 0.0f || fabsf(depth - oldDepth) > dThresh) count++;
+                    }
+            const unsigned int sum = (unsigned int)((2 * structureSize + 1) * (2 * structureSize + 1));
+            out[y * W + x] = ((float)count / (float)sum >= fracReq) ? MINF : oldDepth;
+        }
+}

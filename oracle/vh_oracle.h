@@ -89,6 +89,17 @@ void vho_raycast_render(const VhHashData* hd, const VhHashParams* hp, const VhRa
                         const VhDepthCameraParams* cp, VhRayCastParams* rp,
                         const float lastRigidTransform[16]);
 
+/* Sensor pre-processing, DSC/CameraUtil.cu (host buffers; float4 maps as float[4*n]) */
+void vho_convert_color_raw_to_float4(float* out4, const uint8_t* rgbx, uint32_t width, uint32_t height);                 /* :137-152 */
+void vho_resample_float_map(float* out, uint32_t outW, uint32_t outH, const float* in, uint32_t inW, uint32_t inH);       /* :1071-1118 */
+void vho_resample_float4_map(float* out4, uint32_t outW, uint32_t outH, const float* in4, uint32_t inW, uint32_t inH);    /* :1136-1186 */
+void vho_convert_color_to_intensity_float(float* out, const float* in4, uint32_t width, uint32_t height);                 /* :258-267 */
+void vho_convert_depth_float_to_camera_space_float4(float* out4, const float* in, const VhDepthCameraParams* cp, uint32_t width, uint32_t height); /* :390-407 */
+void vho_gauss_filter_float_map(float* out, const float* in, float sigmaD, float sigmaR, uint32_t width, uint32_t height);   /* :555-593 */
+void vho_gauss_filter_float4_map(float* out4, const float* in4, float sigmaD, float sigmaR, uint32_t width, uint32_t height); /* :611-651 */
+void vho_bilateral_filter_float_map(float* out, const float* in, float sigmaD, float sigmaR, uint32_t width, uint32_t height); /* :446-483 */
+void vho_erode_depth_map(float* out, const float* in, int structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq); /* :1632-1670 */
+
 /* Marching cubes: extractIsoSurfacePass1Kernel + extractIsoSurfacePass2Kernel (DSC/CUDAMarchingCubesSDF.cu:65-121)
  * with extractIsoSurfaceAtPosition / vertexInterp (DSC/MarchingCubesSDFUtil.h:154-262), serially: entries in table
  * order, voxels of a block in thread order (x fastest).  Stores at most maxTriangles triangles and returns the

@@ -1,0 +1,178 @@
+"""Sensor pre-processing: the DSC/CameraUtil.cu kernels between the sensor and integrate().
+
+CPU: the oracle restatement has the expected behaviour on hand-made images.
+GPU: every kernel equals the oracle -- bit for bit where the arithmetic is +,-,*,/ (conversion, resampling,
+intensity, back-projection, erosion); to 1e-5 relative where it goes through exp() (the Gauss / bilateral weights:
+the reference itself builds with -use_fast_math, so nothing tighter is defined) -- and the CUDARGBDSensor pipeline
+equals the composition of the oracle's steps."""
+import numpy as np
+import pytest
+
+from voxelhashing_amd import synth, vhtypes as T
+
+MINF = np.float32(-np.inf)
+
+
+def make_depth(w, h, seed, holes=0.1):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    d = (1.5 + 0.5 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + 0.02 * rng.standard_normal((h, w))).astype(np.float32)
+    d[yy > 0.8 * h] += np.float32(1.0)  # a depth step
+    d[rng.random((h, w)) < holes] = MINF
+    return d
+
+
+def make_color_rgbx(w, h, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    c[rng.random((h, w)) < 0.05, :3] = 0  # black = invalid
+    c[..., 3] = rng.choice(np.array([0, 128, 255], dtype=np.uint8), size=(h, w))
+    return c
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---------------------------------------------------------------------------- CPU
+
+def test_oracle_conversion_and_resampling(oracle_lib):
+    O = oracle_lib
+    c = np.zeros((2, 3, 4), dtype=np.uint8)
+    c[0, 0] = (255, 0, 51, 255)
+    c[0, 1] = (0, 0, 0, 255)      # black -> MINF
+    c[0, 2] = (1, 2, 3, 254)      # alpha: integer division by 255 -> 0
+    f = O.image_op("convert_color_raw_to_float4", c, 3, 2, out_channels=4)
+    assert np.all(f[0, 1] == MINF) and f[0, 0, 0] == 1.0 and f[0, 0, 2] == np.float32(51) / np.float32(255) and f[0, 0, 3] == 1.0
+    assert f[0, 2, 3] == 0.0 and np.all(f[1] == MINF)
+    # same size: resampling is the identity on valid pixels; an invalid neighbour is dropped from the weights
+    d = make_depth(20, 14, 1)
+    r = O.image_op("resample_float_map", d, 20, 14, out_size=(20, 14))
+    assert np.array_equal(bits(r), bits(d))
+    up = O.image_op("resample_float_map", d, 20, 14, out_size=(39, 27))
+    assert np.array_equal(bits(up[::2, ::2]), bits(d))           # scale 19/38 = 0.5 exactly: even pixels hit sources
+    valid = (up != MINF)
+    assert valid.mean() > 0.8 and up[valid].min() >= d[d != MINF].min() - 1e-6 and up[valid].max() <= d[d != MINF].max() + 1e-6
+    inten = O.image_op("convert_color_to_intensity_float", np.ones((4, 5, 4), dtype=np.float32), 5, 4)
+    assert np.allclose(inten, 1.0, atol=1e-6)
+
+
+def test_oracle_filters_and_erosion(oracle_lib):
+    O = oracle_lib
+    d = np.full((15, 15), 2.0, dtype=np.float32)
+    g = O.image_op("gauss_filter_float_map", d, 15, 15, 1.5, 0.1)
+    assert np.allclose(g, 2.0, atol=1e-6)                         # a constant image stays constant
+    d[7, 7] = 3.0                                                 # an outlier beyond sigmaR is ignored by its neighbours
+    g = O.image_op("gauss_filter_float_map", d, 15, 15, 1.5, 0.1)
+    assert np.allclose(np.delete(g.ravel(), 7 * 15 + 7), 2.0, atol=1e-6) and g[7, 7] == 3.0
+    b = O.image_op("bilateral_filter_float_map", d, 15, 15, 1.5, 0.05)
+    assert abs(b[7, 7] - 3.0) < 1e-3 and np.allclose(b[0, 0], 2.0, atol=1e-6)
+    d[3, 3] = MINF
+    assert O.image_op("gauss_filter_float_map", d, 15, 15, 1.5, 0.1)[3, 3] == MINF
+    e = O.image_op("erode_depth_map", d, 15, 15, 1, 0.05, 0.3)
+    assert e[3, 3] == MINF and e[0, 0] == 2.0 and e[7, 7] == MINF  # 8 of 9 neighbours differ from the outlier
+
+
+# ---------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(64, 48), (101, 77), (320, 240)])
+def test_gpu_exact_kernels_match_oracle(vh, oracle_lib, w, h):
+    from voxelhashing_amd import engine as E
+    O = oracle_lib
+    rgbx, depth = make_color_rgbx(w, h, 3), make_depth(w, h, 4)
+    cp = T.make_depth_camera_params(w, h)
+    colf = O.image_op("convert_color_raw_to_float4", rgbx, w, h, out_channels=4)
+    assert np.array_equal(bits(E.image_op("convert_color_raw_to_float4", rgbx, w, h, out_channels=4)), bits(colf))
+    for ow, oh in ((w, h), (w // 2, h // 2), (2 * w - 1, 2 * h - 1), (w + 13, h - 7)):
+        pre = np.full((oh, ow), 7.0, dtype=np.float32)  # pixels the kernel does not write keep their value
+        a = E.image_op("resample_float_map", depth, w, h, out_size=(ow, oh), prefill=pre)
+        b = O.image_op("resample_float_map", depth, w, h, out_size=(ow, oh), prefill=pre)
+        assert np.array_equal(bits(a), bits(b)), f"resample float {w}x{h} -> {ow}x{oh}"
+        pre4 = np.full((oh, ow, 4), 7.0, dtype=np.float32)
+        a = E.image_op("resample_float4_map", colf, w, h, out_channels=4, out_size=(ow, oh), prefill=pre4)
+        b = O.image_op("resample_float4_map", colf, w, h, out_channels=4, out_size=(ow, oh), prefill=pre4)
+        assert np.array_equal(bits(a), bits(b)), f"resample float4 {w}x{h} -> {ow}x{oh}"
+    assert np.array_equal(bits(E.image_op("convert_color_to_intensity_float", colf, w, h)), bits(O.image_op("convert_color_to_intensity_float", colf, w, h)))
+    a = E.image_op("convert_depth_float_to_camera_space_float4", depth, w, h, cp, out_channels=4)
+    b = O.image_op("convert_depth_float_to_camera_space_float4", depth, w, h, cp, out_channels=4)
+    assert np.array_equal(bits(a), bits(b))
+    for size, thr, frac in ((1, 0.05, 0.3), (5, 0.05, 0.3), (2, 0.01, 0.9)):
+        assert np.array_equal(bits(E.image_op("erode_depth_map", depth, w, h, size, thr, frac)), bits(O.image_op("erode_depth_map", depth, w, h, size, thr, frac)))
+    assert np.all(E.image_op("set_invalid_float_map", depth, w, h) == MINF)
+    assert np.array_equal(bits(E.image_op("copy_float_map", depth, w, h)), bits(depth))
+    assert np.array_equal(bits(E.image_op("copy_float4_map", colf, w, h, out_channels=4)), bits(colf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma_d,sigma_r", [(1.0, 0.05), (2.5, 0.1), (0.7, 1.0)])
+def test_gpu_exp_filters_match_oracle_within_tolerance(vh, oracle_lib, sigma_d, sigma_r):
+    """tolerance 1e-5 relative (north star: 1e-4): the weights go through expf/exp, which the two libms round
+    differently in the last place; which pixels are valid must agree exactly"""
+    from voxelhashing_amd import engine as E
+    O = oracle_lib
+    w, h = 96, 72
+    depth = make_depth(w, h, 5)
+    colf = O.image_op("convert_color_raw_to_float4", make_color_rgbx(w, h, 6), w, h, out_channels=4)
+    for name, src, ch, sr in (("gauss_filter_float_map", depth, 1, sigma_r), ("bilateral_filter_float_map", depth, 1, sigma_r),
+                              ("gauss_filter_float4_map", colf, 4, 10.0 * sigma_r)):
+        a = E.image_op(name, src, w, h, sigma_d, sr, out_channels=ch)
+        b = O.image_op(name, src, w, h, sigma_d, sr, out_channels=ch)
+        assert np.array_equal(a == MINF, b == MINF), name
+        ok = b != MINF
+        assert np.allclose(a[ok], b[ok], rtol=1e-5, atol=0.0), f"{name}: max rel {np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok])):.2e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt", [False, True])
+def test_gpu_sensor_pipeline_feeds_integrate(vh, oracle_lib, filt):
+    """CUDARGBDSensor::process == the oracle's steps in the reference's order; its DepthCameraData drives integrate()"""
+    from voxelhashing_amd import engine as E
+    O = oracle_lib
+    sw, sh, aw, ah = 128, 96, 64, 48  # sensor 128x96 -> adapter 64x48
+    fx = fy = 110.0
+    mx, my = (sw - 1) / 2.0, (sh - 1) / 2.0
+    pose = synth.orbit_pose(0)
+    cp_sensor = T.make_depth_camera_params(sw, sh, fx=fx, fy=fy, mx=mx, my=my)
+    depth, color = O.synth_frame(synth.S1_SPHERES, 0, pose, cp_sensor)
+    rgbx = np.ascontiguousarray(np.clip(color * 255.0, 0, 255).astype(np.uint8))
+    rgbx[..., 3] = 255
+    sensor = E.CUDARGBDSensor((sw, sh), (sw, sh), (aw, ah), fx, fy, mx, my, 0.5, 5.0)
+    if filt:
+        sensor.setFiterDepthValues(True, 1.5, 0.1)
+        sensor.setFiterIntensityValues(True, 1.0, 0.5)
+    sensor.process(depth, rgbx)
+    got = sensor.download()
+    cp = sensor.getDepthCameraParams()
+    f32 = np.float32
+    assert cp.m_imageWidth == aw and cp.fx == f32(fx) * (f32(aw) / f32(sw)) and cp.mx == f32(mx) * (f32(aw - 1) / f32(sw - 1))
+    # the oracle's composition
+    colf = O.image_op("convert_color_raw_to_float4", rgbx, sw, sh, out_channels=4)
+    col_rs = O.image_op("resample_float4_map", colf, sw, sh, out_channels=4, out_size=(aw, ah), prefill=np.zeros((ah, aw, 4), np.float32))
+    dep_rs = O.image_op("resample_float_map", depth, sw, sh, out_size=(aw, ah), prefill=np.full((ah, aw), MINF, np.float32))
+    if filt:
+        col_f = O.image_op("gauss_filter_float4_map", col_rs, aw, ah, 1.0, 0.5, out_channels=4)
+        dep_f = O.image_op("gauss_filter_float_map", dep_rs, aw, ah, 1.5, 0.1)
+    else:
+        col_f, dep_f = col_rs, dep_rs
+    inten = O.image_op("convert_color_to_intensity_float", col_f, aw, ah)
+    cam = O.image_op("convert_depth_float_to_camera_space_float4", dep_f, aw, ah, cp, out_channels=4)
+    nrm = O.compute_normals(cam)
+    if not filt:
+        for k, want in (("depth", dep_f), ("color", col_f), ("intensity", inten), ("camera_space", cam), ("normals", nrm)):
+            assert np.array_equal(bits(got[k]), bits(want)), k
+    else:
+        assert np.array_equal(got["depth"] == MINF, dep_f == MINF)
+        ok = dep_f != MINF
+        assert np.allclose(got["depth"][ok], dep_f[ok], rtol=1e-5, atol=0) and np.allclose(got["color"][col_f != MINF], col_f[col_f != MINF], rtol=1e-5, atol=0)
+    # and the frame integrates: the sensor's DepthCameraData is what integrate() takes
+    hp = T.make_hash_params(1 << 12, 1 << 11, **synth.PARAM_SETS["P4"])
+    scene = E.CUDASceneRepHashSDF(hp, T.make_scene_options(offline=True, gc=False))
+    frame = E.DepthFrame(cp, depth_ptr=sensor.getDepthCameraData().d_depthData, color_ptr=sensor.getDepthCameraData().d_colorData)
+    scene.integrate(pose, frame, cp, None)
+    assert scene.getNumOccupiedBlocks() > 30
+    if not filt:
+        o = O.OracleScene(hp, cp, None, T.make_scene_options(offline=True, gc=False))
+        o.integrate(pose, dep_f, col_f)
+        from voxelhashing_amd import canonical
+        canonical.assert_same_scene(scene.state(), o.state(), "sensor-fed integrate")

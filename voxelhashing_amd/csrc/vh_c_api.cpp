@@ -11,6 +11,7 @@
 struct VhSceneRep { CUDASceneRepHashSDF impl; VhSceneRep(const HashParams& p, const VhSceneOptions& o, vhStream_t s) : impl(p, o, s) {} };
 struct VhRayCast { CUDARayCastSDF impl; VhRayCast(const RayCastParams& p, vhStream_t s) : impl(p, s) {} };
 struct VhMarchingCubes { CUDAMarchingCubesHashSDF impl; VhMarchingCubes(const MarchingCubesParams& p, vhStream_t s) : impl(p, s) {} };
+struct VhRGBDSensor { CUDARGBDSensor impl; VhRGBDSensor(const CUDARGBDSensor::Config& c, vhStream_t s) : impl(c, s) {} };
 struct VhChunkGrid {
     CUDASceneRepChunkGrid impl;
     VhChunkGrid(CUDASceneRepHashSDF* s, const vh::vec3f& e, const vh::vec3i& d, const vh::vec3i& m, unsigned int l, bool en, unsigned int parts)
@@ -370,6 +371,58 @@ int vh_marching_cubes_save_mesh(VhMarchingCubes* mc, const char* filename, const
         if (transform) { const vh::mat4f t = toMat(transform); mc->impl.saveMesh(filename, &t, overwriteExistingFile != 0); }
         else mc->impl.saveMesh(filename, nullptr, overwriteExistingFile != 0);
     });
+}
+
+// ---- CUDARGBDSensor ---------------------------------------------------------------
+
+int vh_rgbd_sensor_create(const uint32_t sizes[6], const float intrinsics[6], vhStream_t stream, VhRGBDSensor** out)
+{
+    if (!sizes || !intrinsics || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    CUDARGBDSensor::Config c;
+    std::memset(&c, 0, sizeof(c));
+    c.depthWidth = sizes[0]; c.depthHeight = sizes[1]; c.colorWidth = sizes[2]; c.colorHeight = sizes[3]; c.adapterWidth = sizes[4]; c.adapterHeight = sizes[5];
+    c.fx = intrinsics[0]; c.fy = intrinsics[1]; c.mx = intrinsics[2]; c.my = intrinsics[3]; c.sensorDepthMin = intrinsics[4]; c.sensorDepthMax = intrinsics[5];
+    c.sigmaD = c.sigmaR = c.sigmaDIntensity = c.sigmaRIntensity = 1.0f;
+    return guarded([&] { *out = new VhRGBDSensor(c, stream); });
+}
+void vh_rgbd_sensor_destroy(VhRGBDSensor* s) { delete s; }
+int vh_rgbd_sensor_set_filter_depth_values(VhRGBDSensor* s, int enabled, float sigmaD, float sigmaR)
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    s->impl.setFiterDepthValues(enabled != 0, sigmaD, sigmaR);
+    return VH_OK;
+}
+int vh_rgbd_sensor_set_filter_intensity_values(VhRGBDSensor* s, int enabled, float sigmaD, float sigmaR)
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    s->impl.setFiterIntensityValues(enabled != 0, sigmaD, sigmaR);
+    return VH_OK;
+}
+int vh_rgbd_sensor_process(VhRGBDSensor* s, const float* h_depthFloat, const uint8_t* h_colorRGBX)
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.process(h_depthFloat, h_colorRGBX); });
+}
+int vh_rgbd_sensor_get_depth_camera_data(VhRGBDSensor* s, VhDepthCameraData* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = s->impl.getDepthCameraData();
+    return VH_OK;
+}
+int vh_rgbd_sensor_get_depth_camera_params(VhRGBDSensor* s, VhDepthCameraParams* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = s->impl.getDepthCameraParams();
+    return VH_OK;
+}
+int vh_rgbd_sensor_get_maps(VhRGBDSensor* s, float** d_cameraSpace4, float** d_normals4, float** d_intensity)
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    if (d_cameraSpace4) *d_cameraSpace4 = s->impl.getCameraSpacePositionsFloat4();
+    if (d_normals4) *d_normals4 = s->impl.getNormalMapFloat4();
+    if (d_intensity) *d_intensity = s->impl.getIntensityMapFilteredFloat();
+    return VH_OK;
 }
 
 } // extern "C"

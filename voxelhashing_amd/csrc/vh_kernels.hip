@@ -1554,6 +1554,223 @@ __global__ __launch_bounds__(512) void k_mc_pass2(VhHashData hd, VhHashParams hp
 }
 
 // ---------------------------------------------------------------------------
+// sensor pre-processing (DSC/CameraUtil.cu): the image kernels CUDARGBDAdapter::process and
+// CUDARGBDSensor::process run between the sensor and integrate().  One pixel per lane, rows contiguous across the
+// wave (the reference uses 16x16 tiles); all of them stream the image once.
+// ---------------------------------------------------------------------------
+
+// convertColorRawToFloatDevice :137-152 (RGBX bytes; black means "no colour")
+__global__ __launch_bounds__(256) void k_convert_color_raw_to_float4(float4* out, const uint32_t* in, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = in[i];
+    const uint32_t r = c & 0xffu, g = (c >> 8) & 0xffu, b = (c >> 16) & 0xffu, w = c >> 24;
+    const float mi = minf();
+    out[i] = (r == 0u && g == 0u && b == 0u) ? make_float4(mi, mi, mi, mi)
+                                             : make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)(w / 255u));
+}
+
+// bilinearInterpolationFloat :1071-1098 (invalid taps drop out of the weights)
+VHD float bilinear_float(float x, float y, const float* in, uint32_t W, uint32_t H)
+{
+    const int px = (int)floorf(x), py = (int)floorf(y);
+    const float alpha = x - (float)px, beta = y - (float)py;
+    const float mi = minf();
+    float s0 = 0.0f, w0 = 0.0f, s1 = 0.0f, w1 = 0.0f;
+    if ((uint32_t)px < W && (uint32_t)py < H) { const float v = in[(uint32_t)py * W + (uint32_t)px]; if (v != mi) { s0 += (1.0f - alpha) * v; w0 += (1.0f - alpha); } }
+    if ((uint32_t)(px + 1) < W && (uint32_t)py < H) { const float v = in[(uint32_t)py * W + (uint32_t)(px + 1)]; if (v != mi) { s0 += alpha * v; w0 += alpha; } }
+    if ((uint32_t)px < W && (uint32_t)(py + 1) < H) { const float v = in[(uint32_t)(py + 1) * W + (uint32_t)px]; if (v != mi) { s1 += (1.0f - alpha) * v; w1 += (1.0f - alpha); } }
+    if ((uint32_t)(px + 1) < W && (uint32_t)(py + 1) < H) { const float v = in[(uint32_t)(py + 1) * W + (uint32_t)(px + 1)]; if (v != mi) { s1 += alpha * v; w1 += alpha; } }
+    const float p0 = s0 / w0, p1 = s1 / w1;
+    float ss = 0.0f, ww = 0.0f;
+    if (w0 > 0.0f) { ss += (1.0f - beta) * p0; ww += (1.0f - beta); }
+    if (w1 > 0.0f) { ss += beta * p1; ww += beta; }
+    return ww > 0.0f ? ss / ww : mi;
+}
+
+VHD float4 f4_scale(float a, float4 v) { return make_float4(a * v.x, a * v.y, a * v.z, a * v.w); }
+VHD float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+VHD float4 f4_div(float4 a, float b) { return make_float4(a.x / b, a.y / b, a.z / b, a.w / b); }
+
+// bilinearInterpolationFloat4 :1136-1166
+VHD float4 bilinear_float4(float x, float y, const float4* in, uint32_t W, uint32_t H)
+{
+    const int px = (int)floorf(x), py = (int)floorf(y);
+    const float alpha = x - (float)px, beta = y - (float)py;
+    const float mi = minf();
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float w0 = 0.0f, w1 = 0.0f;
+    auto tap = [&](int tx, int ty, float wgt, float4& s, float& w) {
+        if ((uint32_t)tx < W && (uint32_t)ty < H) {
+            const float4 v = in[(uint32_t)ty * W + (uint32_t)tx];
+            if (v.x != mi && v.y != mi && v.z != mi) { s = f4_add(s, f4_scale(wgt, v)); w += wgt; }
+        }
+    };
+    tap(px, py, 1.0f - alpha, s0, w0);
+    tap(px + 1, py, alpha, s0, w0);
+    tap(px, py + 1, 1.0f - alpha, s1, w1);
+    tap(px + 1, py + 1, alpha, s1, w1);
+    const float4 p0 = f4_div(s0, w0), p1 = f4_div(s1, w1);
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ww = 0.0f;
+    if (w0 > 0.0f) { ss = f4_add(ss, f4_scale(1.0f - beta, p0)); ww += (1.0f - beta); }
+    if (w1 > 0.0f) { ss = f4_add(ss, f4_scale(beta, p1)); ww += beta; }
+    return ww > 0.0f ? f4_div(ss, ww) : make_float4(mi, mi, mi, mi);
+}
+
+// resampleFloatMapDevice :1100-1118 / resampleFloat4MapDevice :1168-1186 (pixels whose nearest source pixel lies
+// outside the source keep their old value, as in the reference)
+template <class T>
+__global__ __launch_bounds__(256) void k_resample(T* out, const T* in, uint32_t inW, uint32_t inH, uint32_t outW, uint32_t outH)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= outW * outH) return;
+    const int x = (int)(i % outW), y = (int)(i / outW);
+    const float scaleWidth = (float)(inW - 1) / (float)(outW - 1), scaleHeight = (float)(inH - 1) / (float)(outH - 1);
+    const uint32_t xInput = (uint32_t)((float)x * scaleWidth + 0.5f), yInput = (uint32_t)((float)y * scaleHeight + 0.5f);
+    if (xInput < inW && yInput < inH) {
+        if constexpr (sizeof(T) == 4) out[i] = bilinear_float((float)x * scaleWidth, (float)y * scaleHeight, in, inW, inH);
+        else out[i] = bilinear_float4((float)x * scaleWidth, (float)y * scaleHeight, in, inW, inH);
+    }
+}
+
+// setInvalidFloatMapDevice :338-346
+__global__ __launch_bounds__(256) void k_set_invalid_float(float* out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = minf();
+}
+
+// convertColorToIntensityFloatDevice :258-267
+__global__ __launch_bounds__(256) void k_color_to_intensity(float* out, const float4* in, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = in[i];
+    out[i] = 0.299f * c.x + 0.587f * c.y + 0.114f * c.z;
+}
+
+// convertDepthFloatToCameraSpaceFloat4Device :390-407
+__global__ __launch_bounds__(256) void k_depth_to_camera_space(float4* out, const float* in, VhDepthCameraParams cp, uint32_t W, uint32_t H)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const float mi = minf();
+    const float depth = in[i];
+    float4 o = make_float4(mi, mi, mi, mi);
+    if (depth != mi) {
+        const F3 p = depth_to_skeleton(cp, i % W, i / W, depth);
+        o = make_float4(p.x, p.y, p.z, 1.0f);
+    }
+    out[i] = o;
+}
+
+// gaussD :436-439 (float exp), gaussR :426-429 (double arithmetic as written)
+VHD float gauss_d(float sigma, int x, int y) { return expf(-((float)(x * x + y * y) / (2.0f * sigma * sigma))); }
+VHD double gauss_r(float sigma, float dist) { return exp(-(double)(dist * dist) / (2.0 * (double)sigma * (double)sigma)); }
+
+// gaussFilterFloatMapDevice :555-593
+__global__ __launch_bounds__(256) void k_gauss_filter_float(float* out, const float* in, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = (int)(i % W), y = (int)(i / W);
+    const int kernelRadius = (int)ceil(2.0 * (double)sigmaD);
+    const float mi = minf();
+    float sum = 0.0f, sumWeight = 0.0f;
+    const float center = in[i];
+    if (center != mi) {
+        for (int m = x - kernelRadius; m <= x + kernelRadius; m++)
+            for (int n = y - kernelRadius; n <= y + kernelRadius; n++)
+                if (m >= 0 && n >= 0 && m < (int)W && n < (int)H) {
+                    const float cur = in[(uint32_t)n * W + (uint32_t)m];
+                    if (cur != mi && fabsf(center - cur) < sigmaR) {
+                        const float weight = gauss_d(sigmaD, m - x, n - y);
+                        sumWeight += weight;
+                        sum += weight * cur;
+                    }
+                }
+    }
+    out[i] = sumWeight > 0.0f ? sum / sumWeight : mi;
+}
+
+// gaussFilterFloat4MapDevice :611-651
+__global__ __launch_bounds__(256) void k_gauss_filter_float4(float4* out, const float4* in, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = (int)(i % W), y = (int)(i / W);
+    const int kernelRadius = (int)ceil(2.0 * (double)sigmaD);
+    const float mi = minf();
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sumWeight = 0.0f;
+    const float4 center = in[i];
+    if (center.x != mi) {
+        for (int m = x - kernelRadius; m <= x + kernelRadius; m++)
+            for (int n = y - kernelRadius; n <= y + kernelRadius; n++)
+                if (m >= 0 && n >= 0 && m < (int)W && n < (int)H) {
+                    const float4 cur = in[(uint32_t)n * W + (uint32_t)m];
+                    if (cur.x != mi) {
+                        const float dx = center.x - cur.x, dy = center.y - cur.y, dz = center.z - cur.z, dw = center.w - cur.w;
+                        if (sqrtf(dx * dx + dy * dy + dz * dz + dw * dw) < sigmaR) { // length(float4), cutil_math.h
+                            const float weight = gauss_d(sigmaD, m - x, n - y);
+                            sumWeight += weight;
+                            sum = f4_add(sum, f4_scale(weight, cur));
+                        }
+                    }
+                }
+    }
+    out[i] = sumWeight > 0.0f ? f4_div(sum, sumWeight) : make_float4(mi, mi, mi, mi);
+}
+
+// bilateralFilterFloatMapDevice :446-483
+__global__ __launch_bounds__(256) void k_bilateral_filter_float(float* out, const float* in, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = (int)(i % W), y = (int)(i / W);
+    const int kernelRadius = (int)ceil(2.0 * (double)sigmaD);
+    const float mi = minf();
+    float sum = 0.0f, sumWeight = 0.0f;
+    const float center = in[i];
+    float o = mi;
+    if (center != mi) {
+        for (int m = x - kernelRadius; m <= x + kernelRadius; m++)
+            for (int n = y - kernelRadius; n <= y + kernelRadius; n++)
+                if (m >= 0 && n >= 0 && m < (int)W && n < (int)H) {
+                    const float cur = in[(uint32_t)n * W + (uint32_t)m];
+                    if (cur != mi) {
+                        const float weight = (float)((double)gauss_d(sigmaD, m - x, n - y) * gauss_r(sigmaR, cur - center));
+                        sumWeight += weight;
+                        sum += weight * cur;
+                    }
+                }
+        if (sumWeight > 0.0f) o = sum / sumWeight;
+    }
+    out[i] = o;
+}
+
+// erodeDepthMapDevice :1632-1670
+__global__ __launch_bounds__(256) void k_erode_depth(float* out, const float* in, int structureSize, int W, int H, float dThresh, float fracReq)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)(W * H)) return;
+    const int x = (int)(idx % (uint32_t)W), y = (int)(idx / (uint32_t)W);
+    const float mi = minf();
+    uint32_t count = 0;
+    const float oldDepth = in[idx];
+    for (int i = -structureSize; i <= structureSize; i++)
+        for (int j = -structureSize; j <= structureSize; j++)
+            if (x + j >= 0 && x + j < W && y + i >= 0 && y + i < H) {
+                const float depth = in[(y + i) * W + (x + j)];
+                if (depth == mi || depth == 0.0f || fabsf(depth - oldDepth) > dThresh) count++;
+            }
+    const uint32_t sum = (uint32_t)((2 * structureSize + 1) * (2 * structureSize + 1));
+    out[idx] = ((float)count / (float)sum >= fracReq) ? mi : oldDepth;
+}
+
+// ---------------------------------------------------------------------------
 // streaming (DSC/CUDASceneRepChunkGrid.cu)
 // ---------------------------------------------------------------------------
 
@@ -1951,6 +2168,92 @@ int vh_extract_iso_surface_pass2(const VhHashData* hd, const VhHashParams* hp, c
     k_mc_pass2<<<numOccupiedBlocks, 512, 0, (hipStream_t)stream>>>(*hd, *hp, *data, numOccupiedBlocks);
     return vh_last_launch_error();
 }
+
+#define VH_IMG_LAUNCH(n) cdiv((uint32_t)(n), 256u), 256, 0, (hipStream_t)stream
+
+int vh_convert_color_raw_to_float4(float* d_output4, const uint8_t* d_inputRGBX, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output4 || !d_inputRGBX) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_convert_color_raw_to_float4<<<VH_IMG_LAUNCH(width * height)>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const uint32_t*>(d_inputRGBX), width * height);
+    return vh_last_launch_error();
+}
+int vh_resample_float_map(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const float* d_input, uint32_t inputWidth, uint32_t inputHeight, vhStream_t stream)
+{
+    if (!d_output || !d_input || inputWidth == 0 || inputHeight == 0) return VH_ERR_BAD_ARGUMENT;
+    if (outputWidth * outputHeight == 0) return VH_OK;
+    k_resample<float><<<VH_IMG_LAUNCH(outputWidth * outputHeight)>>>(d_output, d_input, inputWidth, inputHeight, outputWidth, outputHeight);
+    return vh_last_launch_error();
+}
+int vh_resample_float4_map(float* d_output4, uint32_t outputWidth, uint32_t outputHeight, const float* d_input4, uint32_t inputWidth, uint32_t inputHeight, vhStream_t stream)
+{
+    if (!d_output4 || !d_input4 || inputWidth == 0 || inputHeight == 0) return VH_ERR_BAD_ARGUMENT;
+    if (outputWidth * outputHeight == 0) return VH_OK;
+    k_resample<float4><<<VH_IMG_LAUNCH(outputWidth * outputHeight)>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), inputWidth, inputHeight, outputWidth, outputHeight);
+    return vh_last_launch_error();
+}
+int vh_copy_float_map(float* d_output, const float* d_input, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output || !d_input) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipMemcpyAsync(d_output, d_input, sizeof(float) * (size_t)width * height, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VH_OK;
+}
+int vh_copy_float4_map(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output4 || !d_input4) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipMemcpyAsync(d_output4, d_input4, sizeof(float) * 4 * (size_t)width * height, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VH_OK;
+}
+int vh_set_invalid_float_map(float* d_output, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_set_invalid_float<<<VH_IMG_LAUNCH(width * height)>>>(d_output, width * height);
+    return vh_last_launch_error();
+}
+int vh_convert_color_to_intensity_float(float* d_output, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output || !d_input4) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_color_to_intensity<<<VH_IMG_LAUNCH(width * height)>>>(d_output, reinterpret_cast<const float4*>(d_input4), width * height);
+    return vh_last_launch_error();
+}
+int vh_convert_depth_float_to_camera_space_float4(float* d_output4, const float* d_input, const VhDepthCameraParams* cp, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output4 || !d_input || !cp) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_depth_to_camera_space<<<VH_IMG_LAUNCH(width * height)>>>(reinterpret_cast<float4*>(d_output4), d_input, *cp, width, height);
+    return vh_last_launch_error();
+}
+int vh_gauss_filter_float_map(float* d_output, const float* d_input, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output || !d_input || d_output == d_input) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_gauss_filter_float<<<VH_IMG_LAUNCH(width * height)>>>(d_output, d_input, sigmaD, sigmaR, width, height);
+    return vh_last_launch_error();
+}
+int vh_gauss_filter_float4_map(float* d_output4, const float* d_input4, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output4 || !d_input4 || d_output4 == d_input4) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_gauss_filter_float4<<<VH_IMG_LAUNCH(width * height)>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), sigmaD, sigmaR, width, height);
+    return vh_last_launch_error();
+}
+int vh_bilateral_filter_float_map(float* d_output, const float* d_input, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!d_output || !d_input || d_output == d_input) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_bilateral_filter_float<<<VH_IMG_LAUNCH(width * height)>>>(d_output, d_input, sigmaD, sigmaR, width, height);
+    return vh_last_launch_error();
+}
+int vh_erode_depth_map(float* d_output, const float* d_input, int32_t structureSize, uint32_t width, uint32_t height, float dThresh, float fracReq, vhStream_t stream)
+{
+    if (!d_output || !d_input || d_output == d_input || structureSize < 0) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_erode_depth<<<VH_IMG_LAUNCH(width * height)>>>(d_output, d_input, structureSize, (int)width, (int)height, dThresh, fracReq);
+    return vh_last_launch_error();
+}
+#undef VH_IMG_LAUNCH
 
 int vh_stream_out_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start,
                         float radius, const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_output,

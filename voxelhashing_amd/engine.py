@@ -514,3 +514,90 @@ class CUDAMarchingCubesHashSDF:
     def saveMesh(self, filename, transform=None, overwriteExistingFile=False):
         t = f16(transform) if transform is not None else None
         check(self.L.vh_marching_cubes_save_mesh(self.handle, filename.encode(), t, int(overwriteExistingFile)), "saveMesh")
+
+
+# ---- sensor pre-processing (DSC/CameraUtil.cu) over the C ABI: numpy in, numpy out (tests, tools) ----
+
+def image_op(name, src, width, height, *args, out_channels=1, out_size=None, prefill=None):
+    """run vh_<name> on one source image; -> float32 array (height, width[, 4]) of the output size"""
+    L = load()
+    src = np.ascontiguousarray(src)
+    d_in = DeviceBuffer.from_numpy(src)
+    ow, oh = out_size if out_size else (width, height)
+    n_out = ow * oh * out_channels
+    d_out = DeviceBuffer(n_out * 4)
+    if prefill is not None:
+        d_out.upload(np.ascontiguousarray(prefill, dtype=np.float32))
+    fn = getattr(L, "vh_" + name)
+    if name in ("resample_float_map", "resample_float4_map"):
+        check(fn(d_out.ptr, ow, oh, d_in.ptr, width, height, None), name)
+    elif name == "convert_depth_float_to_camera_space_float4":
+        check(fn(d_out.ptr, d_in.ptr, C.byref(args[0]), width, height, None), name)
+    elif name == "erode_depth_map":
+        check(fn(d_out.ptr, d_in.ptr, int(args[0]), width, height, float(args[1]), float(args[2]), None), name)
+    elif name in ("gauss_filter_float_map", "gauss_filter_float4_map", "bilateral_filter_float_map"):
+        check(fn(d_out.ptr, d_in.ptr, float(args[0]), float(args[1]), width, height, None), name)
+    elif name == "set_invalid_float_map":
+        check(fn(d_out.ptr, width, height, None), name)
+    else:
+        check(fn(d_out.ptr, d_in.ptr, width, height, None), name)
+    out = d_out.download(np.float32, n_out)
+    return out.reshape((oh, ow, out_channels)) if out_channels > 1 else out.reshape((oh, ow))
+
+
+class CUDARGBDSensor:
+    """Mirror of CUDARGBDSensor over CUDARGBDAdapter (include/vh.hpp) over the C ABI."""
+
+    def __init__(self, depth_size, color_size, adapter_size, fx, fy, mx, my, depth_min, depth_max, stream=None):
+        self.L = load()
+        self.size = tuple(adapter_size)
+        sizes = (C.c_uint32 * 6)(depth_size[0], depth_size[1], color_size[0], color_size[1], adapter_size[0], adapter_size[1])
+        intr = (C.c_float * 6)(fx, fy, mx, my, depth_min, depth_max)
+        h = C.c_void_p()
+        check(self.L.vh_rgbd_sensor_create(sizes, intr, stream, C.byref(h)), "vh_rgbd_sensor_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_rgbd_sensor_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setFiterDepthValues(self, b=True, sigmaD=1.0, sigmaR=1.0):
+        check(self.L.vh_rgbd_sensor_set_filter_depth_values(self.handle, int(b), sigmaD, sigmaR), "setFiterDepthValues")
+
+    def setFiterIntensityValues(self, b=True, sigmaD=1.0, sigmaR=1.0):
+        check(self.L.vh_rgbd_sensor_set_filter_intensity_values(self.handle, int(b), sigmaD, sigmaR), "setFiterIntensityValues")
+
+    def process(self, depth_float, color_rgbx):
+        d = np.ascontiguousarray(depth_float, dtype=np.float32)
+        c = np.ascontiguousarray(color_rgbx, dtype=np.uint8)
+        check(self.L.vh_rgbd_sensor_process(self.handle, d.ctypes.data, c.ctypes.data), "process")
+
+    def getDepthCameraData(self):
+        out = T.DepthCameraData()
+        check(self.L.vh_rgbd_sensor_get_depth_camera_data(self.handle, C.byref(out)), "getDepthCameraData")
+        return out
+
+    def getDepthCameraParams(self):
+        out = T.DepthCameraParams()
+        check(self.L.vh_rgbd_sensor_get_depth_camera_params(self.handle, C.byref(out)), "getDepthCameraParams")
+        return out
+
+    def download(self):
+        W, H = self.size
+        cam = self.getDepthCameraData()
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self.L.vh_rgbd_sensor_get_maps(self.handle, C.byref(a), C.byref(b), C.byref(c)), "get_maps")
+        return dict(
+            depth=download(cam.d_depthData, np.float32, W * H).reshape(H, W),
+            color=download(cam.d_colorData, np.float32, W * H * 4).reshape(H, W, 4),
+            camera_space=download(a.value, np.float32, W * H * 4).reshape(H, W, 4),
+            normals=download(b.value, np.float32, W * H * 4).reshape(H, W, 4),
+            intensity=download(c.value, np.float32, W * H).reshape(H, W),
+        )

@@ -77,6 +77,26 @@ PROTOTYPES = {
     "vh_raycast_set_timing": (C.c_int, [_VP, C.c_int]),
     "vh_raycast_set_timing_stride": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "vh_raycast_set_interval_splatting": (C.c_int, [_VP, C.c_int]),
+    "vh_convert_color_raw_to_float4": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_resample_float_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_resample_float4_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_copy_float_map": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_copy_float4_map": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_set_invalid_float_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_convert_color_to_intensity_float": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_convert_depth_float_to_camera_space_float4": (C.c_int, [_VP, _VP, P(T.DepthCameraParams), C.c_uint32, C.c_uint32, _VP]),
+    "vh_gauss_filter_float_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
+    "vh_gauss_filter_float4_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
+    "vh_bilateral_filter_float_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
+    "vh_erode_depth_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _VP]),
+    "vh_rgbd_sensor_create": (C.c_int, [P(C.c_uint32), P(C.c_float), _VP, P(_VP)]),
+    "vh_rgbd_sensor_destroy": (None, [_VP]),
+    "vh_rgbd_sensor_set_filter_depth_values": (C.c_int, [_VP, C.c_int, C.c_float, C.c_float]),
+    "vh_rgbd_sensor_set_filter_intensity_values": (C.c_int, [_VP, C.c_int, C.c_float, C.c_float]),
+    "vh_rgbd_sensor_process": (C.c_int, [_VP, _VP, _VP]),
+    "vh_rgbd_sensor_get_depth_camera_data": (C.c_int, [_VP, P(T.DepthCameraData)]),
+    "vh_rgbd_sensor_get_depth_camera_params": (C.c_int, [_VP, P(T.DepthCameraParams)]),
+    "vh_rgbd_sensor_get_maps": (C.c_int, [_VP, P(_VP), P(_VP), P(_VP)]),
     "vh_marching_cubes_data_alloc": (C.c_int, [P(T.MarchingCubesData), P(T.MarchingCubesParams)]),
     "vh_marching_cubes_data_free": (None, [P(T.MarchingCubesData)]),
     "vh_marching_cubes_update_params": (C.c_int, [P(T.MarchingCubesData), P(T.MarchingCubesParams), _VP]),
