@@ -267,6 +267,18 @@ int vh_bilateral_filter_float_map(float* d_output, const float* d_input, float s
 int vh_erode_depth_map(float* d_output, const float* d_input, int32_t structureSize, uint32_t width, uint32_t height, float dThresh,
                        float fracReq, vhStream_t stream);                                                                       /* :1672 */
 
+/* ---- parameter files: zParameters*.txt as mLib's ParameterFile reads them
+ * (DSCroot/Include/mLib/include/core-util/parameterFile.h:22-60,136-172: per line, cut at the first "//", "#" or ";",
+ * strip blanks / quotes / semicolons, split at the first "="; numbers by stoi / stof, bool false iff "false", "False" or
+ * "0") and the parametersFromGlobalAppState builders of the host classes. */
+int vh_app_state_read(const char* filename, VhAppState* out);
+int vh_app_state_parse(const char* text, VhAppState* out); /* the same on a string */
+void vh_hash_params_from_app_state(const VhAppState* gas, VhHashParams* out);        /* DSC/CUDASceneRepHashSDF.h:38-58 */
+void vh_raycast_params_from_app_state(const VhAppState* gas, const float intrinsics[16], const float intrinsicsInv[16],
+                                      VhRayCastParams* out);                          /* DSC/CUDARayCastSDF.h:24-40 */
+void vh_marching_cubes_params_from_app_state(const VhAppState* gas, VhMarchingCubesParams* out); /* DSC/CUDAMarchingCubesHashSDF.h:19-28 */
+void vh_scene_options_from_app_state(const VhAppState* gas, VhSceneOptions* out);
+
 /* handle level: CUDARGBDSensor over CUDARGBDAdapter (include/vh.hpp).  config = {depthW, depthH, colorW, colorH, adapterW,
  * adapterH} and {fx, fy, mx, my, sensorDepthMin, sensorDepthMax}. */
 typedef struct VhRGBDSensor VhRGBDSensor;

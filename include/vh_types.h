@@ -211,6 +211,37 @@ typedef struct VhSceneOptions {
     uint32_t s_streamingOutParts;
 } VhSceneOptions;
 
+/* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt
+ * file by vh_app_state_read.  A key the file does not hold is value-initialised (0 / false), as readMembers() does
+ * (DSC/GlobalAppState.h:139-142). */
+typedef struct VhAppState {
+    uint32_t s_adapterWidth, s_adapterHeight;
+    float s_sensorDepthMax, s_sensorDepthMin;
+    float s_SDFVoxelSize, s_SDFMarchingCubeThreshFactor, s_SDFTruncation, s_SDFTruncationScale, s_SDFMaxIntegrationDistance;
+    uint32_t s_SDFIntegrationWeightSample, s_SDFIntegrationWeightMax;
+    uint32_t s_hashNumBuckets, s_hashNumSDFBlocks, s_hashMaxCollisionLinkedListSize;
+    float s_SDFRayIncrementFactor, s_SDFRayThresSampleDistFactor, s_SDFRayThresDistFactor;
+    uint32_t s_SDFUseGradients;
+    float s_depthSigmaD, s_depthSigmaR;
+    uint32_t s_depthFilter;
+    float s_colorSigmaD, s_colorSigmaR;
+    uint32_t s_colorFilter;
+    uint32_t s_integrationEnabled, s_trackingEnabled, s_timingsDetailledEnabled, s_timingsTotalEnabled;
+    uint32_t s_garbageCollectionEnabled, s_garbageCollectionStarve;
+    uint32_t s_marchingCubesMaxNumTriangles;
+    uint32_t s_streamingEnabled;
+    float s_streamingVoxelExtents[3];
+    int32_t s_streamingGridDimensions[3];
+    int32_t s_streamingMinGridPos[3];
+    uint32_t s_streamingInitialChunkListSize;
+    float s_streamingRadius;
+    float s_streamingPos[3];
+    uint32_t s_streamingOutParts;
+    uint32_t s_offlineProcessing;
+    uint32_t s_sensorIdx;
+    uint32_t numKeysFound; /* how many of the members above the file held */
+} VhAppState;
+
 /* Error codes of the C ABI: 0 ok; <0 = -(hipError_t); >0 logical. */
 enum {
     VH_OK = 0,

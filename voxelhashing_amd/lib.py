@@ -89,6 +89,12 @@ PROTOTYPES = {
     "vh_gauss_filter_float4_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "vh_bilateral_filter_float_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "vh_erode_depth_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _VP]),
+    "vh_app_state_read": (C.c_int, [C.c_char_p, P(T.AppState)]),
+    "vh_app_state_parse": (C.c_int, [C.c_char_p, P(T.AppState)]),
+    "vh_hash_params_from_app_state": (None, [P(T.AppState), P(T.HashParams)]),
+    "vh_raycast_params_from_app_state": (None, [P(T.AppState), P(C.c_float), P(C.c_float), P(T.RayCastParams)]),
+    "vh_marching_cubes_params_from_app_state": (None, [P(T.AppState), P(T.MarchingCubesParams)]),
+    "vh_scene_options_from_app_state": (None, [P(T.AppState), P(T.SceneOptions)]),
     "vh_rgbd_sensor_create": (C.c_int, [P(C.c_uint32), P(C.c_float), _VP, P(_VP)]),
     "vh_rgbd_sensor_destroy": (None, [_VP]),
     "vh_rgbd_sensor_set_filter_depth_values": (C.c_int, [_VP, C.c_int, C.c_float, C.c_float]),

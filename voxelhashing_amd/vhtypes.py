@@ -130,6 +130,28 @@ class MarchingCubesData(C.Structure):
 TRIANGLE_DTYPE = np.dtype([("v", [("p", np.float32, 3), ("c", np.float32, 3)], 3)])
 
 
+class AppState(C.Structure):
+    _fields_ = [
+        ("s_adapterWidth", C.c_uint32), ("s_adapterHeight", C.c_uint32),
+        ("s_sensorDepthMax", C.c_float), ("s_sensorDepthMin", C.c_float),
+        ("s_SDFVoxelSize", C.c_float), ("s_SDFMarchingCubeThreshFactor", C.c_float), ("s_SDFTruncation", C.c_float),
+        ("s_SDFTruncationScale", C.c_float), ("s_SDFMaxIntegrationDistance", C.c_float),
+        ("s_SDFIntegrationWeightSample", C.c_uint32), ("s_SDFIntegrationWeightMax", C.c_uint32),
+        ("s_hashNumBuckets", C.c_uint32), ("s_hashNumSDFBlocks", C.c_uint32), ("s_hashMaxCollisionLinkedListSize", C.c_uint32),
+        ("s_SDFRayIncrementFactor", C.c_float), ("s_SDFRayThresSampleDistFactor", C.c_float), ("s_SDFRayThresDistFactor", C.c_float),
+        ("s_SDFUseGradients", C.c_uint32),
+        ("s_depthSigmaD", C.c_float), ("s_depthSigmaR", C.c_float), ("s_depthFilter", C.c_uint32),
+        ("s_colorSigmaD", C.c_float), ("s_colorSigmaR", C.c_float), ("s_colorFilter", C.c_uint32),
+        ("s_integrationEnabled", C.c_uint32), ("s_trackingEnabled", C.c_uint32), ("s_timingsDetailledEnabled", C.c_uint32),
+        ("s_timingsTotalEnabled", C.c_uint32), ("s_garbageCollectionEnabled", C.c_uint32), ("s_garbageCollectionStarve", C.c_uint32),
+        ("s_marchingCubesMaxNumTriangles", C.c_uint32), ("s_streamingEnabled", C.c_uint32),
+        ("s_streamingVoxelExtents", C.c_float * 3), ("s_streamingGridDimensions", C.c_int32 * 3), ("s_streamingMinGridPos", C.c_int32 * 3),
+        ("s_streamingInitialChunkListSize", C.c_uint32), ("s_streamingRadius", C.c_float), ("s_streamingPos", C.c_float * 3),
+        ("s_streamingOutParts", C.c_uint32), ("s_offlineProcessing", C.c_uint32), ("s_sensorIdx", C.c_uint32),
+        ("numKeysFound", C.c_uint32),
+    ]
+
+
 class SceneOptions(C.Structure):
     _fields_ = [
         ("s_offlineProcessing", C.c_uint8),
