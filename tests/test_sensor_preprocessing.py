@@ -105,7 +105,7 @@ def test_gpu_exact_kernels_match_oracle(vh, oracle_lib, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sigma_d,sigma_r", [(1.0, 0.05), (2.5, 0.1), (0.7, 1.0)])
+@pytest.mark.parametrize("sigma_d,sigma_r", [(1.0, 0.05), (2.5, 0.1), (0.7, 1.0), (4.5, 0.2)])  # 4.5: radius 9, the untiled kernel
 def test_gpu_exp_filters_match_oracle_within_tolerance(vh, oracle_lib, sigma_d, sigma_r):
     """tolerance 1e-5 relative (north star: 1e-4): the weights go through expf/exp, which the two libms round
     differently in the last place; which pixels are valid must agree exactly"""

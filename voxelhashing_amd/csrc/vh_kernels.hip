@@ -1695,6 +1695,45 @@ __global__ __launch_bounds__(256) void k_gauss_filter_float(float* out, const fl
     out[i] = sumWeight > 0.0f ? sum / sumWeight : mi;
 }
 
+// The same filter for radii up to kGaussMaxRadius with the neighbourhood and the weights in LDS: a workgroup owns a
+// 32x8 tile of pixels, stages the tile plus its halo once and computes the (2r+1)^2 weights once instead of once per
+// pixel (the expf is most of the per-pixel kernel's work).  Same taps in the same order, same weights: same sums.
+constexpr int kGaussMaxRadius = 8, kGaussTileW = 32, kGaussTileH = 8;
+
+__global__ __launch_bounds__(256) void k_gauss_filter_float_tiled(float* out, const float* in, float sigmaD, float sigmaR, int W, int H, int r)
+{
+    extern __shared__ float sGauss[];
+    const int tw = kGaussTileW + 2 * r, th = kGaussTileH + 2 * r, side = 2 * r + 1;
+    float* sTile = sGauss;              // tw x th, rows contiguous
+    float* sWeight = sGauss + tw * th;  // side x side, [dx + r][dy + r]
+    const int x0 = (int)blockIdx.x * kGaussTileW, y0 = (int)blockIdx.y * kGaussTileH;
+    const float mi = minf();
+    for (int i = (int)threadIdx.x; i < tw * th; i += 256) {
+        const int gx = x0 - r + i % tw, gy = y0 - r + i / tw;
+        sTile[i] = (gx >= 0 && gy >= 0 && gx < W && gy < H) ? in[(size_t)gy * W + gx] : mi; // outside the image: skipped like an invalid pixel
+    }
+    for (int i = (int)threadIdx.x; i < side * side; i += 256) sWeight[i] = gauss_d(sigmaD, i / side - r, i % side - r);
+    __syncthreads();
+    const int lx = (int)threadIdx.x % kGaussTileW, ly = (int)threadIdx.x / kGaussTileW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= W || y >= H) return;
+    float sum = 0.0f, sumWeight = 0.0f;
+    const float center = sTile[(ly + r) * tw + lx + r];
+    if (center != mi) {
+        for (int dx = -r; dx <= r; dx++)      // m = x + dx outer, n = y + dy inner: the reference's order of summation
+            for (int dy = -r; dy <= r; dy++) {
+                const float cur = sTile[(ly + r + dy) * tw + lx + r + dx];
+                // a tap outside the image holds MINF here; the reference skips it by its bounds test
+                if (cur != mi && fabsf(center - cur) < sigmaR) {
+                    const float weight = sWeight[(dx + r) * side + dy + r];
+                    sumWeight += weight;
+                    sum += weight * cur;
+                }
+            }
+    }
+    out[(size_t)y * W + x] = sumWeight > 0.0f ? sum / sumWeight : mi;
+}
+
 // gaussFilterFloat4MapDevice :611-651
 __global__ __launch_bounds__(256) void k_gauss_filter_float4(float4* out, const float4* in, float sigmaD, float sigmaR, uint32_t W, uint32_t H)
 {
@@ -2229,7 +2268,14 @@ int vh_gauss_filter_float_map(float* d_output, const float* d_input, float sigma
 {
     if (!d_output || !d_input || d_output == d_input) return VH_ERR_BAD_ARGUMENT;
     if (width * height == 0) return VH_OK;
-    k_gauss_filter_float<<<VH_IMG_LAUNCH(width * height)>>>(d_output, d_input, sigmaD, sigmaR, width, height);
+    const int r = (int)ceil(2.0 * (double)sigmaD);
+    if (r >= 0 && r <= kGaussMaxRadius) {
+        const size_t lds = sizeof(float) * ((size_t)(kGaussTileW + 2 * r) * (kGaussTileH + 2 * r) + (size_t)(2 * r + 1) * (2 * r + 1));
+        const dim3 grid(cdiv(width, (uint32_t)kGaussTileW), cdiv(height, (uint32_t)kGaussTileH));
+        k_gauss_filter_float_tiled<<<grid, 256, lds, (hipStream_t)stream>>>(d_output, d_input, sigmaD, sigmaR, (int)width, (int)height, r);
+    } else {
+        k_gauss_filter_float<<<VH_IMG_LAUNCH(width * height)>>>(d_output, d_input, sigmaD, sigmaR, width, height);
+    }
     return vh_last_launch_error();
 }
 int vh_gauss_filter_float4_map(float* d_output4, const float* d_input4, float sigmaD, float sigmaR, uint32_t width, uint32_t height, vhStream_t stream)
