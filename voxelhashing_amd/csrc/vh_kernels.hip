@@ -619,23 +619,15 @@ __global__ __launch_bounds__(256) void k_interval_clear(uint4* heads, uint32_t n
 // ray caster (renderKernel DSC/CUDARayCastSDF.cu:18-57,
 // traverseCoarseGridSimpleSampleAll DSC/RayCastSDFUtil.h:198-262)
 //
-// One wave per 8x8 pixel tile (rays of a tile stay in the same few blocks).
-// The reference's march is a chain of dependent gathers (8 hash probes x up to
-// 11 entry loads + 8 voxel loads per sample, one after the other).  On MI355X
-// that chain, not bandwidth or ALU, sets the kernel time (rocprof: ~137
-// serialized loads per wave), so the work is re-ordered to put independent
-// loads in flight together -- without changing a single arithmetic operation,
-// its order, or an early-out:
-//   * empty space: the first tap of the next 4 samples is resolved at once
-//     (block id -> occupancy bit of its bucket: one cached dword each); a
-//     sample whose first tap has no block is invalid, exactly as in the
-//     reference, and costs no table access;
-//   * a sample with a first tap: block pointers of the (1..8) blocks the 8
-//     taps touch come from a 2-entry per-ray cache or a bucket probe; then all
-//     8 voxels are loaded together and weighted/accumulated in the reference's
-//     tap order;
-//   * march and bisection share ONE sample-evaluation site (a small state
-//     machine), which keeps the kernel at a few dozen VGPRs.
+// One wave per 8x8 pixel tile (the rays of a tile stay in the same few blocks).  The reference's march is a chain
+// of dependent gathers (8 hash probes x up to 11 entry loads + 8 voxel loads per sample, one after the other); here
+// the work is re-ordered without changing an arithmetic operation, its order, or an early-out:
+//   * k_render (with the tile heads / block lists of k_interval_splat): block -> pointer through a per-wave table in
+//     LDS, the march confined to the tile's depth interval, one probe and one round of LDS reads per sample;
+//   * k_render_hash (no intervals: the reference fork's behaviour): block -> pointer through the hash table behind
+//     a 2-entry per-ray cache, empty space skipped on the bucket occupancy bit;
+//   * both: division-free tap coordinates where they can be certified, the eight voxels of a sample in flight
+//     together as 8-byte loads, march-until-sign-change / bisect / resume so that the lanes of a wave bisect together.
 // ---------------------------------------------------------------------------
 
 struct BlockCache {
@@ -719,11 +711,6 @@ struct HashLookup {
     }
 };
 
-__device__ __noinline__ int lookup_ptr_slow(const VhHashData hd, const VhHashParams hp, int bx, int by, int bz)
-{
-    return lookup_ptr(hd, hp, mki3(bx, by, bz));
-}
-
 // block -> voxel pointers through the tile's own table in LDS, built from the tile's block list (open addressing).
 // A slot is kTileSlotWords words: {x, y, z, p000, p100, p010, p110, p001, p101, p011, p111, -}: the block, its voxel
 // pointer and the pointers of its seven +x/+y/+z neighbours (VH_FREE_ENTRY where there is none), so that a sample
@@ -798,9 +785,6 @@ struct TileLookup {
 // two words, and the sdf word is then fetched only after the weight test -- a second trip to memory per sample.
 VHD uint2 load_voxel(const VhHashData& hd, int ptr, int lx, int ly, int lz)
 {
-#if defined(VH_EXP) && VH_EXP == 2
-    return make_uint2(__float_as_uint(0.05f - 0.01f * (float)((ptr >> 9) & 7) + 0.001f * (float)(lx + ly + lz)), 0x10808080u);
-#endif
     const unsigned long long v = __hip_atomic_load(
         reinterpret_cast<const unsigned long long*>(&hd.d_SDFBlocks[(uint32_t)ptr + (uint32_t)(lz * 64 + ly * 8 + lx)]),
         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -876,7 +860,7 @@ VHD bool trilinear(const VhHashData& hd, float vs, LK& lk, int p0in, const Taps&
 // The same function with the reference's tap-by-tap early-out, leaving the
 // partial sum in `dist` on failure: gradientForPoint (:174-195) ignores the
 // return value and uses that partial sum.
-__device__ __noinline__ float trilinear_partial(const VhHashData hd, const VhHashParams hp, BlockCache bc, float px, float py, float pz)
+__device__ __noinline__ float trilinear_partial(const VhHashData hd, const VhHashParams hp, float px, float py, float pz)
 {
     const float vs = hp.m_virtualVoxelSize;
     const float oSet = vs;
@@ -904,15 +888,15 @@ __device__ __noinline__ float trilinear_partial(const VhHashData hd, const VhHas
 }
 
 // gradientForPoint :174-195
-VHD F3 gradient_for_point(const VhHashData& hd, const VhHashParams& hp, const BlockCache& bc, F3 pos)
+VHD F3 gradient_for_point(const VhHashData& hd, const VhHashParams& hp, F3 pos)
 {
     const float vs = hp.m_virtualVoxelSize;
-    const float dp00 = trilinear_partial(hd, hp, bc, pos.x - 0.5f * vs, pos.y - 0.0f, pos.z - 0.0f);
-    const float d0p0 = trilinear_partial(hd, hp, bc, pos.x - 0.0f, pos.y - 0.5f * vs, pos.z - 0.0f);
-    const float d00p = trilinear_partial(hd, hp, bc, pos.x - 0.0f, pos.y - 0.0f, pos.z - 0.5f * vs);
-    const float d100 = trilinear_partial(hd, hp, bc, pos.x + 0.5f * vs, pos.y + 0.0f, pos.z + 0.0f);
-    const float d010 = trilinear_partial(hd, hp, bc, pos.x + 0.0f, pos.y + 0.5f * vs, pos.z + 0.0f);
-    const float d001 = trilinear_partial(hd, hp, bc, pos.x + 0.0f, pos.y + 0.0f, pos.z + 0.5f * vs);
+    const float dp00 = trilinear_partial(hd, hp, pos.x - 0.5f * vs, pos.y - 0.0f, pos.z - 0.0f);
+    const float d0p0 = trilinear_partial(hd, hp, pos.x - 0.0f, pos.y - 0.5f * vs, pos.z - 0.0f);
+    const float d00p = trilinear_partial(hd, hp, pos.x - 0.0f, pos.y - 0.0f, pos.z - 0.5f * vs);
+    const float d100 = trilinear_partial(hd, hp, pos.x + 0.5f * vs, pos.y + 0.0f, pos.z + 0.0f);
+    const float d010 = trilinear_partial(hd, hp, pos.x + 0.0f, pos.y + 0.5f * vs, pos.z + 0.0f);
+    const float d001 = trilinear_partial(hd, hp, pos.x + 0.0f, pos.y + 0.0f, pos.z + 0.5f * vs);
     const F3 g = mk3((dp00 - d100) / vs, (d0p0 - d010) / vs, (d00p - d001) / vs);
     const float l = sqrtf(dot3(g, g));
     if (l == 0.0f) return mk3(0.0f, 0.0f, 0.0f);
@@ -1011,11 +995,7 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
     // (they are invalid: lastValid = 0), samples after it likewise, so nothing can be hit there.  rcur still
     // advances by the same sequence of additions, one VALU op per skipped sample.
     const float tSkip = depthToRayLength * tileZmin;
-#if defined(VH_EXP) && VH_EXP == 4
-    const float tStop = fminf(rayEnd, tSkip + 2.0f * inc);
-#else
     const float tStop = fminf(rayEnd, depthToRayLength * tileZmax);
-#endif
 #pragma unroll 1
     while (rcur < tSkip && rcur < rayEnd) rcur += inc;
 
@@ -1089,9 +1069,7 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
             out.color = color2;
             if (GRADIENTS) {
                 const F3 iso = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
-                BlockCache unused;
-                cache_init(unused);
-                const F3 g = gradient_for_point(hd, hp, unused, iso);
+                const F3 g = gradient_for_point(hd, hp, iso);
                 out.normal = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
             }
             break;
@@ -1189,9 +1167,6 @@ void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraPar
     }
     if (tile >= nTiles) return;
     int* tab = tileTab[threadIdx.x / kWave];
-#if defined(VH_EXP) && VH_EXP == 8
-    if (tile < 0x7fffffffu) return;
-#endif
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
     const float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y);
