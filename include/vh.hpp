@@ -163,7 +163,10 @@ private:
     bool m_timeMarchOnly;
     unsigned int m_timeStride, m_renderCalls;
     uint32_t* d_tileHeads;     // {min, max camera depth, block count, 0} per 8x8-pixel tile
-    VhTileBlock* d_tileBlocks; // VH_TILE_LIST_CAPACITY blocks per tile
+    VhTileBlock* d_tileBlocks; // up to VH_TILE_LIST_CAPACITY_LARGE blocks per tile
+    uint32_t *h_longestList, *d_longestList; // mapped host word: longest tile list the ray caster met lately
+    bool m_largeTables;        // current choice of table size
+    uint32_t m_quietFrames, m_tileCapacity;
     uint32_t* d_schedule;      // tiles by cost class, for the launch order of the next render()
     uint32_t m_phase;          // render() calls with intervals so far
     bool m_useIntervals;

@@ -106,14 +106,18 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
  * this fork leaves disabled.  Per 8x8-pixel tile (ceil(W/8)*ceil(H/8) of them, row-major):
  *   d_tileHeads   4 words: {min, max} camera depth (float bits) of the allocated blocks the tile's rays can read,
  *                 their number, 0;
- *   d_tileBlocks  tileCapacity entries: those blocks (may be NULL: intervals only).  Lists longer than
- *                 min(tileCapacity, VH_TILE_LIST_CAPACITY) are ignored by the ray caster (it probes the hash).
+ *   d_tileBlocks  tileCapacity entries: those blocks (may be NULL: intervals only).  tileCapacity also picks the
+ *                 ray caster's table size: up to VH_TILE_LIST_CAPACITY (64) small tables, above it large ones
+ *                 (VH_TILE_LIST_CAPACITY_LARGE, 128).  A longer list is used as far as it fits; the blocks it could
+ *                 not hold are looked up in the hash table.
+ *   d_longestList (splat, with a schedule; may be NULL) receives the longest list the previous render met if it came
+ *                 within 16 of the small capacity, else 0: what a host needs to choose the capacity.
  * Both are conservative (every allocated block, grown by the reach of a sample), so rendering with them gives
  * bit-identical maps.  vh_render_intervals consumes and re-arms the heads; vh_ray_interval_clear arms them once. */
 int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height, vhStream_t stream);
 int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, const VhRayCastParams* rp,
                           uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, uint32_t* d_schedule, uint32_t phase,
-                          vhStream_t stream);
+                          uint32_t* d_longestList, vhStream_t stream);
 /* d_schedule (may be NULL) is vh_render_schedule_bytes() of device memory, zeroed once, that belongs to one sequence
  * of splat + render calls; phase is that sequence's call counter (1, 2, 3, ...; the same value for the splat and the
  * render of one frame).  The ray caster stores the cost every tile had; the next splat sorts the tiles by it and

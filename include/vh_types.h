@@ -153,7 +153,8 @@ typedef struct VhRayCastData {
 /* SDFBlockDesc, DSC/CUDASceneRepChunkGrid.cu:13-16 / .h:24-51 (16 B):
  * streaming wire/disk unit, together with a 4096 B block of 512 voxels. */
 /* ray-interval splatting (vh_ray_interval_splat): one entry of a tile's block list */
-#define VH_TILE_LIST_CAPACITY 64
+#define VH_TILE_LIST_CAPACITY 64        /* small tile tables (default) */
+#define VH_TILE_LIST_CAPACITY_LARGE 128 /* large tile tables: fine voxels */
 typedef struct VhTileBlock {
     int32_t pos[3]; /* SDF block position */
     int32_t ptr;    /* its voxel pointer (HashEntry::ptr) */

@@ -74,6 +74,7 @@ def test_interval_splatting_does_not_change_a_bit(vh, cfg, scene_name):
     L = lib.load()
     n_tiles = ((cp.m_imageWidth + 7) // 8) * ((cp.m_imageHeight + 7) // 8)
     heads, small_lists = lib.DeviceBuffer(n_tiles * 16), lib.DeviceBuffer(n_tiles * 3 * 16)
+    big_lists = lib.DeviceBuffer(n_tiles * 128 * 16)
     lib.check(L.vh_ray_interval_clear(heads.ptr, cp.m_imageWidth, cp.m_imageHeight, None))
     views = [poses[-1], synth.orbit_pose(40, 200, radius), synth.orbit_pose(3, 200, radius * 1.7)]
     tilt = np.array(poses[2], dtype=np.float32).reshape(4, 4).copy()
@@ -90,11 +91,12 @@ def test_interval_splatting_does_not_change_a_bit(vh, cfg, scene_name):
         ma, mb = ray.download(), full.download()
         assert_maps_equal(ma, mb, f"view {i}: intervals vs full range")
         hits += int((ma["depth"] != -np.inf).sum())
-        # launcher level: lists that overflow (capacity 3: misses fall back to the hash table) and no lists at all
+        # launcher level: lists that overflow (capacity 3: misses fall back to the hash table), no lists at all, and the
+        # large tables (capacity 128 and an odd 100)
         hd, hpp, rpp, rd = scene.getHashData(), scene.getHashParams(), full.getRayCastParams(), full.getRayCastData()
-        for cap, blocks in ((3, small_lists), (0, None)):
+        for cap, blocks in ((3, small_lists), (0, None), (128, big_lists), (100, big_lists)):
             lib.check(L.vh_ray_interval_splat(C.byref(hd), C.byref(hpp), C.byref(cp), C.byref(rpp), heads.ptr,
-                                              blocks.ptr if blocks else None, cap, None, 0, None))
+                                              blocks.ptr if blocks else None, cap, None, 0, None, None))
             lib.check(L.vh_render_intervals(C.byref(hd), C.byref(hpp), C.byref(rd), C.byref(cp), C.byref(rpp), heads.ptr,
                                             blocks.ptr if blocks else None, cap, None, 0, None))
             mc = full.download()

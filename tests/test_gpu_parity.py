@@ -131,6 +131,28 @@ def test_ray_intervals_on_ragged_image_sizes(E, oracle_lib, width, height, param
     assert hits > 0.2 * width * height
 
 
+def test_fine_voxels_switch_to_large_tile_tables(E, oracle_lib):
+    """1 cm voxels at 320x240: some tiles list more than 64 blocks.  The first renders use the small tables (overflow:
+    hash fallback), the ray caster's feedback then selects the large ones; every render equals the full-range march."""
+    hp = T.make_hash_params(1 << 16, 1 << 14, **synth.PARAM_SETS["P1"])
+    cp = T.make_depth_camera_params(320, 240)
+    rp = T.make_raycast_params(hp, cp)
+    scene = E.CUDASceneRepHashSDF(hp, T.make_scene_options(offline=True, gc=False))
+    frame = E.DepthFrame(cp)
+    poses = [synth.orbit_pose(k, n_frames=60) for k in range(3)]
+    for pose in poses:
+        E.synth_frame(synth.S1_SPHERES, 0, pose, cp, out=frame)
+        scene.integrate(pose, frame, cp, None)
+    ray, full = E.CUDARayCastSDF(rp), E.CUDARayCastSDF(rp)
+    full.setIntervalSplatting(False)
+    full.render(scene.getHashData(), scene.getHashParams(), cp, poses[-1])
+    want = full.download()
+    assert (want["depth"] != -np.inf).sum() > 5000
+    for i in range(6):
+        ray.render(scene.getHashData(), scene.getHashParams(), cp, poses[-1])
+        assert_maps_equal(ray.download(), want, f"render {i}")
+
+
 @pytest.mark.parametrize("voxel,buckets", [(0.04, 500000), (0.01, 2000000), (0.02, 1 << 18), (0.004, 1 << 14), (0.035, 7)])
 def test_exact_shortcuts(vh, voxel, buckets):
     """div_exact == `/` and umod_fast == `%` bit for bit on 16 M pseudo-random operands"""

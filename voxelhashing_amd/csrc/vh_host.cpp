@@ -554,7 +554,14 @@ CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
     m_useIntervals = true;
     const size_t tiles = (size_t)((params.m_width + 7) / 8) * ((params.m_height + 7) / 8);
     checkHip(hipMalloc((void**)&d_tileHeads, sizeof(uint32_t) * 4 * (tiles ? tiles : 1)), "tile heads");
-    checkHip(hipMalloc((void**)&d_tileBlocks, sizeof(VhTileBlock) * VH_TILE_LIST_CAPACITY * (tiles ? tiles : 1)), "tile block lists");
+    checkHip(hipMalloc((void**)&d_tileBlocks, sizeof(VhTileBlock) * VH_TILE_LIST_CAPACITY_LARGE * (tiles ? tiles : 1)), "tile block lists");
+    h_longestList = nullptr;
+    d_longestList = nullptr;
+    m_largeTables = false;
+    m_quietFrames = 0;
+    checkHip(hipHostMalloc((void**)&h_longestList, sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc");
+    *h_longestList = 0;
+    checkHip(hipHostGetDevicePointer((void**)&d_longestList, h_longestList, 0), "hipHostGetDevicePointer");
     check(vh_ray_interval_clear(d_tileHeads, params.m_width, params.m_height, m_stream), "vh_ray_interval_clear");
     d_schedule = nullptr;
     m_phase = 0;
@@ -574,6 +581,7 @@ CUDARayCastSDF::~CUDARayCastSDF()
     if (d_tileHeads) (void)hipFree(d_tileHeads);
     if (d_tileBlocks) (void)hipFree(d_tileBlocks);
     if (d_schedule) (void)hipFree(d_schedule);
+    if (h_longestList) (void)hipHostFree(h_longestList);
 }
 
 void CUDARayCastSDF::setTiming(bool on, bool marchOnly, unsigned int stride)
@@ -610,12 +618,18 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     if (m_useIntervals) {
         if (timedAll) m_timer->start(ST_SPLAT, (hipStream_t)m_stream);
         ++m_phase;
-        check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, d_schedule, m_phase, m_stream), "rayIntervalSplatCUDA");
+        // Table size for this frame, from what the ray caster reported two frames ago (mapped host word, no
+        // synchronisation): large tables as soon as a list outgrew the small ones, back after 30 frames without one.
+        const uint32_t longest = *(volatile uint32_t*)h_longestList;
+        if (longest > (uint32_t)VH_TILE_LIST_CAPACITY) { m_largeTables = true; m_quietFrames = 0; }
+        else if (m_largeTables && ++m_quietFrames > 30) m_largeTables = false;
+        m_tileCapacity = m_largeTables ? VH_TILE_LIST_CAPACITY_LARGE : VH_TILE_LIST_CAPACITY;
+        check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, d_longestList, m_stream), "rayIntervalSplatCUDA");
         if (timedAll) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
     }
     if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
     if (m_useIntervals) {
-        check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, VH_TILE_LIST_CAPACITY, d_schedule, m_phase, m_stream), "renderCS");
+        check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, m_stream), "renderCS");
     } else {
         check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
     }

@@ -433,12 +433,16 @@ constexpr uint32_t kCostClassWidth = 8;
 // class the previous k_render stored, dearest first, dealt to the workgroups (4 tiles each) in rows of numCUs that
 // alternate direction.  The hardware places workgroup g on compute unit g mod numCUs (all of them are resident), so
 // a compute unit receives one workgroup of every row: the dearest of one row with the cheapest of the next.
-__device__ void schedule_tiles(uint32_t* sched, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t* sCount /*[2 * 256]*/)
+__device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t* sCount /*[2 * 256]*/)
 {
     // layout: {phase the slots were made for, -, -, -}, cost class per tile, {tile, phase} per launch slot
     const uint32_t* cls = sched + 4;
     uint2* slots = reinterpret_cast<uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u));
-    if (threadIdx.x == 0) sched[0] = phase;
+    if (threadIdx.x == 0) {
+        sched[0] = phase;
+        if (feedback) *feedback = sched[1]; // longest tile list the previous k_render met (0: none near the small capacity)
+        sched[1] = 0u;
+    }
     // counting sort with kSub sub-bins per class (keyed by the thread): 64 lanes adding to one LDS word serialise
     constexpr uint32_t kSub = 8, kBins = kCostClasses * kSub;
     static_assert(kBins == 4u * kWave, "the scan below gives four bins to each lane of one wave");
@@ -510,7 +514,7 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t nTiles, uint32_t phase,
 
 __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
                                                         VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap,
-                                                        uint32_t* sched, uint32_t phase, uint32_t numCUs, uint32_t nSplatGroups)
+                                                        uint32_t* sched, uint32_t phase, uint32_t numCUs, uint32_t nSplatGroups, uint32_t* feedback)
 {
     __shared__ uint32_t sBuckets[kSplatWordsPerGroup * 32];
     __shared__ int4 sBlocks[kSplatQueue];
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
     const float growLo = (rp.m_useGradients ? 1.75f : 1.25f) * vs, growHi = (rp.m_useGradients ? 0.75f : 0.25f) * vs;
 
     if (blockIdx.x >= nSplatGroups) { // the extra workgroup (launched only with a schedule)
-        schedule_tiles(sched, (uint32_t)(tilesX * tilesY), phase, numCUs, sBuckets);
+        schedule_tiles(sched, feedback, (uint32_t)(tilesX * tilesY), phase, numCUs, sBuckets);
         return;
     }
     if (threadIdx.x == 0) { sNumBuckets = 0u; sNumBlocks = 0u; }
@@ -663,7 +667,6 @@ VHD int cached_lookup(const VhHashData& hd, const VhHashParams& hp, HashMod hm, 
 }
 
 constexpr int kPtrUnknown = -3; // "first tap not resolved yet" (never a block pointer, VH_FREE_ENTRY or VH_LOCK_ENTRY)
-constexpr uint32_t kTileTabSlots = 2 * VH_TILE_LIST_CAPACITY; // LDS table per wave: load factor <= 1/2
 
 // block -> voxel pointer through the hash table in HBM
 struct HashLookup {
@@ -719,6 +722,7 @@ struct HashLookup {
 // allocated; when the list overflowed, the table holds a part of it and a miss falls back to the hash table.
 constexpr uint32_t kTileSlotWords = 12;
 
+template <uint32_t kTileTabSlots> // 2 x the list capacity (load factor <= 1/2), a power of two
 struct TileLookup {
     const int* tab;
     bool complete;
@@ -1145,12 +1149,17 @@ __global__ __launch_bounds__(256) void k_render_hash(VhHashData hd, VhHashParams
 // block table in LDS and marches inside the tile's depth interval.  5 waves per SIMD keep all tiles of a 640x480
 // frame resident at once (4800 waves <= 5 x 4 x 256): the march is a latency chain, and a second round of waves
 // costs as much as the first.
-template <bool GRADIENTS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
-void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
-              uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase)
+template <bool GRADIENTS, uint32_t CAP>
+VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCastData& rd, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
+                     uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase,
+                     int (*tileTab)[2u * CAP * 12u])
 {
-    __shared__ int tileTab[256 / kWave][kTileTabSlots * kTileSlotWords];
+    // CAP = blocks a tile's table takes: 64 (6 KB of LDS per wave, every tile of a 640x480 frame resident) or 128 (12 KB:
+    // three workgroups per compute unit; for fine voxels, where a few tiles see more than 64 blocks and would
+    // otherwise probe the hash table for every block the table could not hold)
+    constexpr uint32_t kTileTabSlots = 2u * CAP;
+    typedef TileLookup<kTileTabSlots> Lookup;
+    static_assert(kTileSlotWords == 12u, "tileTab row size");
     const uint32_t lane = lane_id();
     const uint32_t W = rp.m_width, H = rp.m_height;
     const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
@@ -1171,27 +1180,43 @@ void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraPar
     const uint4 head = heads[tile];
     const float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y);
     if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
-    const uint32_t listed = min(head.z, min(cap, (uint32_t)VH_TILE_LIST_CAPACITY));
+    const uint32_t listed = min(head.z, min(cap, CAP));
     const bool complete = listed == head.z;
-    int4 mine = make_int4(0, 0, 0, VH_FREE_ENTRY);
-    if (lane < listed) mine = lists[(size_t)tile * cap + lane];
+    // feedback for the host's choice of CAP: the longest list of the frame (only lists near the small capacity report)
+    if (sched && lane == 0 && head.z > (uint32_t)VH_TILE_LIST_CAPACITY - 16u) atomicMax(&sched[1], head.z);
     for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i * kTileSlotWords + 3u] = VH_FREE_ENTRY;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t h = TileLookup::slot_of(mine.x, mine.y, mine.z);
-    if (lane < listed) {
-        // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
-        while (atomicCAS(&tab[h * kTileSlotWords + 3u], VH_FREE_ENTRY, mine.w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
-        tab[h * kTileSlotWords + 0u] = mine.x; tab[h * kTileSlotWords + 1u] = mine.y; tab[h * kTileSlotWords + 2u] = mine.z;
+    constexpr uint32_t kPerLane = CAP / kWave; // list entries per lane
+    int4 mine[kPerLane];
+    uint32_t slot[kPerLane];
+#pragma unroll
+    for (uint32_t k = 0; k < kPerLane; k++) {
+        const uint32_t i = lane + k * kWave;
+        mine[k] = make_int4(0, 0, 0, VH_FREE_ENTRY);
+        slot[k] = 0u;
+        if (i < listed) {
+            mine[k] = lists[(size_t)tile * cap + i];
+            uint32_t h = Lookup::slot_of(mine[k].x, mine[k].y, mine[k].z);
+            // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
+            while (atomicCAS(&tab[h * kTileSlotWords + 3u], VH_FREE_ENTRY, mine[k].w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
+            tab[h * kTileSlotWords + 0u] = mine[k].x; tab[h * kTileSlotWords + 1u] = mine[k].y; tab[h * kTileSlotWords + 2u] = mine[k].z;
+            slot[k] = h;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < listed && complete) {
+    if (complete) {
         // pointers of the seven neighbours a sample in this block can straddle into
+#pragma unroll
+        for (uint32_t k = 0; k < kPerLane; k++) {
+            if (lane + k * kWave < listed) {
 #pragma unroll 1
-        for (uint32_t k = 1; k < 8u; k++) {
-            const int sl = TileLookup::slot_find(tab, mine.x + (int)(k & 1u), mine.y + (int)((k >> 1) & 1u), mine.z + (int)((k >> 2) & 1u));
-            tab[h * kTileSlotWords + 3u + k] = sl >= 0 ? tab[(uint32_t)sl * kTileSlotWords + 3u] : VH_FREE_ENTRY;
+                for (uint32_t j = 1; j < 8u; j++) {
+                    const int sl = Lookup::slot_find(tab, mine[k].x + (int)(j & 1u), mine[k].y + (int)((j >> 1) & 1u), mine[k].z + (int)((j >> 2) & 1u));
+                    tab[slot[k] * kTileSlotWords + 3u + j] = sl >= 0 ? tab[(uint32_t)sl * kTileSlotWords + 3u] : VH_FREE_ENTRY;
+                }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1205,7 +1230,7 @@ void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraPar
     out.hit = false;
     uint32_t cost = 0u;
     if (inImage && tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
-        TileLookup lk{ tab, complete, hd, hp };
+        Lookup lk{ tab, complete, hd, hp };
         march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out, cost VH_STAT_ARGS);
     }
     if (inImage) {
@@ -1221,6 +1246,27 @@ void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraPar
 #undef VH_STAT_DECL
 #undef VH_STAT_ARGS
 #undef VH_STAT_STORE
+
+// small tables: 5 waves per SIMD keep all tiles of a 640x480 frame resident at once (4800 waves <= 5 x 4 x 256): the
+// march is a latency chain, and a second round of waves costs as much as the first
+template <bool GRADIENTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
+              uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase)
+{
+    __shared__ int tileTab[256 / kWave][2u * VH_TILE_LIST_CAPACITY * kTileSlotWords];
+    render_tile<GRADIENTS, VH_TILE_LIST_CAPACITY>(hd, hp, rd, cp, rp, heads, lists, cap, sched, phase, tileTab);
+}
+
+// large tables (48 KB of LDS per workgroup: three workgroups per compute unit)
+template <bool GRADIENTS>
+__global__ __launch_bounds__(256)
+void k_render_large(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
+                    uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase)
+{
+    __shared__ int tileTab[256 / kWave][2u * VH_TILE_LIST_CAPACITY_LARGE * kTileSlotWords];
+    render_tile<GRADIENTS, VH_TILE_LIST_CAPACITY_LARGE>(hd, hp, rd, cp, rp, heads, lists, cap, sched, phase, tileTab);
+}
 
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
 __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height)
@@ -2116,8 +2162,17 @@ int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRa
     uint4* h = reinterpret_cast<uint4*>(d_tileHeads);
     const int4* l = reinterpret_cast<const int4*>(d_tileBlocks);
     const uint32_t cap = d_tileBlocks ? tileCapacity : 0u;
-    if (rp->m_useGradients) k_render<true><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
-    else k_render<false><<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+    // the capacity of the lists picks the table size: up to VH_TILE_LIST_CAPACITY the small tables, beyond it the large ones
+    const bool large = cap > (uint32_t)VH_TILE_LIST_CAPACITY;
+    const dim3 grid(cdiv(tiles, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (rp->m_useGradients) {
+        if (large) k_render_large<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+        else k_render<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+    } else {
+        if (large) k_render_large<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+        else k_render<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+    }
     return vh_last_launch_error();
 }
 
@@ -2132,7 +2187,7 @@ int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height
 
 int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp, const VhRayCastParams* rp,
                           uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity, uint32_t* d_schedule, uint32_t phase,
-                          vhStream_t stream)
+                          uint32_t* d_longestList, vhStream_t stream)
 {
     if (!hd || !hp || !cp || !rp || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     if (rp->m_width == 0 || rp->m_height == 0) return VH_OK;
@@ -2146,7 +2201,7 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
     const uint32_t groups = cdiv(nWords, kSplatWordsPerGroup);
     k_interval_splat<<<groups + (d_schedule ? 1u : 0u), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
                                                                                  reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u,
-                                                                                 d_schedule, phase, (uint32_t)(numCUs > 0 ? numCUs : 256), groups);
+                                                                                 d_schedule, phase, (uint32_t)(numCUs > 0 ? numCUs : 256), groups, d_longestList);
     return vh_last_launch_error();
 }
 

@@ -44,7 +44,7 @@ PROTOTYPES = {
     "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP, _VP]),
     "vh_render": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP]),
     "vh_ray_interval_clear": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
-    "vh_ray_interval_splat": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP]),
+    "vh_ray_interval_splat": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP]),
     "vh_render_intervals": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP]),
     "vh_render_schedule_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
