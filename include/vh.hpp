@@ -439,4 +439,34 @@ private:
     float *d_depthData, *d_colorData; // what m_depthCameraData points to
 };
 
+
+// ---------------------------------------------------------------------------
+// CUDACameraTrackingMultiRes (DSC/CUDACameraTrackingMultiRes.{h,cpp}): coarse-to-fine projective point-to-plane ICP of
+// the sensor frame (camera-space positions + normals) against the ray-cast model maps.  The per-level settings the
+// reference takes from GlobalCameraTrackingState (and passes in five vectors) travel as one VhTrackingState.
+class CUDACameraTrackingMultiRes {
+public:
+    CUDACameraTrackingMultiRes(unsigned int imageWidth, unsigned int imageHeight, unsigned int levels, vhStream_t stream = nullptr);
+    ~CUDACameraTrackingMultiRes();
+    CUDACameraTrackingMultiRes(const CUDACameraTrackingMultiRes&) = delete;
+    CUDACameraTrackingMultiRes& operator=(const CUDACameraTrackingMultiRes&) = delete;
+
+    // applyCT :241-289.  Returns lastTransform * delta; a matrix of -inf when tracking was lost (isTrackingLost).
+    vh::mat4f applyCT(float* dInput, float* dInputNormals, float* dModel, float* dModelNormals, const vh::mat4f& lastTransform,
+                      const VhTrackingState& settings, const vh::mat4f& deltaTransformEstimate, const DepthCameraParams& depthCameraParams);
+    static bool isTrackingLost(const vh::mat4f& m);
+    const VhIcpState& getLastState() const { return m_lastState; } // LinearSystemConfidence of the last solve + iteration count
+    unsigned int getLevels() const { return m_levels; }
+
+private:
+    unsigned int m_levels;
+    vhStream_t m_stream;
+    std::vector<unsigned int> m_imageWidth, m_imageHeight;
+    std::vector<float*> d_correspondence, d_correspondenceNormal, d_input, d_inputNormal, d_model, d_modelNormal;
+    float* d_partials;
+    VhIcpState* d_state;
+    float* d_deltaEstimate;
+    VhIcpState m_lastState;
+};
+
 #endif // VH_HPP

@@ -296,6 +296,39 @@ int vh_rgbd_sensor_get_depth_camera_params(VhRGBDSensor* s, VhDepthCameraParams*
 /* device maps at adapter resolution: {camera space float4, normals float4, intensity float} */
 int vh_rgbd_sensor_get_maps(VhRGBDSensor* s, float** d_cameraSpace4, float** d_normals4, float** d_intensity);
 
+/* ---- projective ICP camera tracking.  Launcher level: the steps of one alignment, each a kernel
+ * that reads and updates a VhIcpState in device memory (a step returns at once when the state says "lost" or "level
+ * done"), so that a whole multi-resolution solve runs without a host round trip.
+ *   vh_icp_projective_correspondences  projectiveCorrespondences           DSC/CUDAImageHelper.cu:70-145
+ *   vh_icp_build_linear_system         buildLinearSystem (per-wave terms)  DSC/CUDABuildLinearSystem.cu:130-204
+ *   vh_icp_solve                       reductionSystemCPU + computeBestRigidAlignment + delinearizeTransformation +
+ *                                      the early-out of align               DSC/CUDABuildLinearSystem.cpp:52-92,
+ *                                                                           DSC/CUDACameraTrackingMultiRes.cpp:186-253,306-318 */
+int vh_icp_begin(VhIcpState* d_state, const float* d_deltaEstimate16, vhStream_t stream);
+int vh_icp_begin_level(VhIcpState* d_state, vhStream_t stream);
+int vh_icp_projective_correspondences(const float* d_input4, const float* d_inputNormals4, const float* d_target4, const float* d_targetNormals4,
+                                      float* d_output4, float* d_outputNormals4, uint32_t width, uint32_t height, float distThres, float normalThres,
+                                      float levelFactor, const VhIcpState* d_state, const VhDepthCameraParams* cp, vhStream_t stream);
+uint32_t vh_icp_num_partials(uint32_t width, uint32_t height); /* rows of 30 floats vh_icp_build_linear_system writes */
+int vh_icp_build_linear_system(uint32_t width, uint32_t height, float* d_partials, const float* d_input4, const float* d_corr4,
+                               const float* d_corrNormals4, const VhIcpState* d_state, vhStream_t stream);
+int vh_icp_solve(VhIcpState* d_state, const float* d_partials, uint32_t numPartials, float angleThres, float distThres, float earlyOutResidual,
+                 int lastInnerIteration, vhStream_t stream);
+/* GlobalCameraTrackingState::readMembers on zParametersTracking*.txt (DSC/GlobalCameraTrackingState.h:14-60) */
+int vh_tracking_state_read(const char* filename, VhTrackingState* out);
+int vh_tracking_state_parse(const char* text, VhTrackingState* out);
+
+/* handle level: CUDACameraTrackingMultiRes (DSC/CUDACameraTrackingMultiRes.h:17-78) */
+typedef struct VhCameraTracking VhCameraTracking;
+int vh_camera_tracking_create(uint32_t imageWidth, uint32_t imageHeight, uint32_t levels, vhStream_t stream, VhCameraTracking** out);
+void vh_camera_tracking_destroy(VhCameraTracking* t);
+/* applyCT(dInput, dInputNormals, -, dModel, dModelNormals, -, lastTransform, <per-level settings>, condThres, angleThres,
+ * deltaTransformEstimate, ...) :241-289: returns lastTransform * delta in transformOut, every entry -inf if tracking was lost
+ * (trackingLost = 1).  state (may be NULL) receives the final VhIcpState. */
+int vh_camera_tracking_apply_ct(VhCameraTracking* t, float* d_input4, float* d_inputNormals4, float* d_model4, float* d_modelNormals4,
+                                const float lastTransform[16], const VhTrackingState* settings, const float deltaTransformEstimate[16],
+                                const VhDepthCameraParams* cp, float transformOut[16], int* trackingLost, VhIcpState* state);
+
 /* ---- marching cubes -------------------------------------------------------------------------
  * launcher level: resetMarchingCubesCUDA / extractIsoSurfacePass1CUDA / extractIsoSurfacePass2CUDA
  * (DSC/CUDAMarchingCubesSDF.cu:29-40, 94-105, 132-143).  The reference passes a RayCastData only for its member

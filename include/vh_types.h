@@ -243,6 +243,35 @@ typedef struct VhAppState {
     uint32_t numKeysFound; /* how many of the members above the file held */
 } VhAppState;
 
+/* GlobalCameraTrackingState (DSC/GlobalCameraTrackingState.h:14-25), per pyramid level; from zParametersTracking*.txt */
+#define VH_TRACKING_MAX_LEVELS 8
+typedef struct VhTrackingState {
+    uint32_t s_maxLevels;
+    uint32_t s_maxOuterIter[VH_TRACKING_MAX_LEVELS];
+    uint32_t s_maxInnerIter[VH_TRACKING_MAX_LEVELS];
+    float s_distThres[VH_TRACKING_MAX_LEVELS];
+    float s_normalThres[VH_TRACKING_MAX_LEVELS];
+    float s_angleTransThres[VH_TRACKING_MAX_LEVELS];
+    float s_distTransThres[VH_TRACKING_MAX_LEVELS];
+    float s_residualEarlyOut[VH_TRACKING_MAX_LEVELS];
+    uint32_t numLevelsFound; /* how many levels of s_maxOuterIter the file held */
+} VhTrackingState;
+
+/* Device-resident state of one camera-tracking solve (vh_icp_*): the delta transform being refined and what the
+ * reference keeps in LinearSystemConfidence (DSC/ICPErrorLog.h:16-58). */
+typedef struct VhIcpState {
+    float delta[16];        /* row-major; input points are moved by it */
+    float lastError;        /* lastICPError of the current level (-1 at its start) */
+    uint32_t done;          /* current level left its outer loop early (residual early-out) */
+    uint32_t lost;          /* tracking lost: singular system or a step beyond the level's thresholds */
+    float sumRegError;
+    float sumRegWeight;
+    uint32_t numCorr;
+    float matrixCondition;
+    uint32_t iterations;    /* linear systems solved so far */
+    uint32_t pad[8];
+} VhIcpState;
+
 /* Error codes of the C ABI: 0 ok; <0 = -(hipError_t); >0 logical. */
 enum {
     VH_OK = 0,

@@ -12,6 +12,7 @@ struct VhSceneRep { CUDASceneRepHashSDF impl; VhSceneRep(const HashParams& p, co
 struct VhRayCast { CUDARayCastSDF impl; VhRayCast(const RayCastParams& p, vhStream_t s) : impl(p, s) {} };
 struct VhMarchingCubes { CUDAMarchingCubesHashSDF impl; VhMarchingCubes(const MarchingCubesParams& p, vhStream_t s) : impl(p, s) {} };
 struct VhRGBDSensor { CUDARGBDSensor impl; VhRGBDSensor(const CUDARGBDSensor::Config& c, vhStream_t s) : impl(c, s) {} };
+struct VhCameraTracking { CUDACameraTrackingMultiRes impl; VhCameraTracking(unsigned int w, unsigned int h, unsigned int l, vhStream_t s) : impl(w, h, l, s) {} };
 struct VhChunkGrid {
     CUDASceneRepChunkGrid impl;
     VhChunkGrid(CUDASceneRepHashSDF* s, const vh::vec3f& e, const vh::vec3i& d, const vh::vec3i& m, unsigned int l, bool en, unsigned int parts)
@@ -423,6 +424,29 @@ int vh_rgbd_sensor_get_maps(VhRGBDSensor* s, float** d_cameraSpace4, float** d_n
     if (d_normals4) *d_normals4 = s->impl.getNormalMapFloat4();
     if (d_intensity) *d_intensity = s->impl.getIntensityMapFilteredFloat();
     return VH_OK;
+}
+
+// ---- CUDACameraTrackingMultiRes -----------------------------------------------------
+
+int vh_camera_tracking_create(uint32_t imageWidth, uint32_t imageHeight, uint32_t levels, vhStream_t stream, VhCameraTracking** out)
+{
+    if (!out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] { *out = new VhCameraTracking(imageWidth, imageHeight, levels, stream); });
+}
+void vh_camera_tracking_destroy(VhCameraTracking* t) { delete t; }
+int vh_camera_tracking_apply_ct(VhCameraTracking* t, float* d_input4, float* d_inputNormals4, float* d_model4, float* d_modelNormals4,
+                                const float lastTransform[16], const VhTrackingState* settings, const float deltaTransformEstimate[16],
+                                const VhDepthCameraParams* cp, float transformOut[16], int* trackingLost, VhIcpState* state)
+{
+    if (!t || !lastTransform || !settings || !cp || !transformOut) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        const vh::mat4f est = deltaTransformEstimate ? toMat(deltaTransformEstimate) : vh::mat4f::identity();
+        const vh::mat4f r = t->impl.applyCT(d_input4, d_inputNormals4, d_model4, d_modelNormals4, toMat(lastTransform), *settings, est, *cp);
+        std::memcpy(transformOut, r.m, sizeof(r.m));
+        if (trackingLost) *trackingLost = CUDACameraTrackingMultiRes::isTrackingLost(r) ? 1 : 0;
+        if (state) *state = t->impl.getLastState();
+    });
 }
 
 } // extern "C"

@@ -1831,6 +1831,227 @@ __global__ __launch_bounds__(256) void k_erode_depth(float* out, const float* in
 }
 
 // ---------------------------------------------------------------------------
+// projective ICP camera tracking: projectiveCorrespondencesKernel (DSC/CUDAImageHelper.cu:70-125),
+// scanScanElementsCS + reductionSystemCPU (DSC/CUDABuildLinearSystem.cu:130-188, .cpp:52-92) and the 6x6 solve /
+// delinearisation the reference does on the host with Eigen (DSC/CUDACameraTrackingMultiRes.cpp:186-253).
+//
+// The reference copies every linear system to the host, solves it there and uploads the next transform: up to 18
+// blocking round trips per frame.  Here the transform, the residual history and the lost / early-out flags live in
+// a VhIcpState on the device; every step is a kernel on the stream that reads and updates it, a step whose level has
+// finished returns at once, and the host reads the result once per frame.
+// ---------------------------------------------------------------------------
+
+constexpr uint32_t kIcpWindow = 12;   // pixels a lane sums before the wave reduces (localWindowSize, .cpp:41)
+constexpr uint32_t kIcpTerms = 30;    // 21 upper-triangle terms of A^T A, 6 of A^T b, residual, weight, count (ARRAY_SIZE)
+
+__global__ void k_icp_begin(VhIcpState* st, const float* d_deltaEstimate)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 16u) st->delta[t] = d_deltaEstimate[t];
+    if (t == 0u) { st->lost = 0u; st->done = 0u; st->lastError = -1.0f; st->iterations = 0u; st->sumRegError = 0.0f; st->sumRegWeight = 0.0f; st->numCorr = 0u; st->matrixCondition = 0.0f; }
+}
+
+__global__ void k_icp_begin_level(VhIcpState* st)
+{
+    if (threadIdx.x == 0u) { st->done = 0u; st->lastError = -1.0f; }
+}
+
+// projectiveCorrespondencesKernel :70-125 (getBestCorrespondence1x1 = the target pixel itself)
+__global__ __launch_bounds__(256) void k_icp_correspondences(const float4* input, const float4* inputNormals, const float4* target, const float4* targetNormals,
+                                                             float4* outCorr, float4* outCorrNormals, uint32_t W, uint32_t H, float distThres,
+                                                             float normalThres, float levelFactor, const VhIcpState* st, VhDepthCameraParams cp)
+{
+    if (st->lost || st->done) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const float mi = minf();
+    float4 oc = make_float4(mi, mi, mi, mi), on = oc;
+    const float4 p = input[i], n = inputNormals[i];
+    if (p.x != mi && n.x != mi) {
+        const F3 pt = mat_mul_p(st->delta, mk3(p.x, p.y, p.z)), nt = mat_mul_d(st->delta, mk3(n.x, n.y, n.z));
+        // cameraToKinectScreenInt, DSC/DepthCameraUtil.h:74-85, then the division by the level factor (both truncate)
+        int sx = f2i((pt.x * cp.fx / pt.z + cp.mx) + 0.5f), sy = f2i((pt.y * cp.fy / pt.z + cp.my) + 0.5f);
+        sx = f2i((float)sx / levelFactor); sy = f2i((float)sy / levelFactor);
+        if (sx >= 0 && sy >= 0 && sx < (int)W && sy < (int)H) {
+            const float4 tp = target[(uint32_t)sy * W + (uint32_t)sx];
+            float4 tn = targetNormals[(uint32_t)sy * W + (uint32_t)sx];
+            if (tp.x != mi && tn.x != mi) {
+                const float dx = pt.x - tp.x, dy = pt.y - tp.y, dz = pt.z - tp.z;
+                const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float dNormal = nt.x * tn.x + nt.y * tn.y + nt.z * tn.z;
+                if (d <= distThres && dNormal >= normalThres) {
+                    oc = tp;
+                    tn.w = fmaxf(0.0f, 0.5f * ((1.0f - d / distThres) + (1.0f - cam_to_proj_z(cp, pt.z)))); // weight of the pair
+                    on = tn;
+                }
+            }
+        }
+    }
+    outCorr[i] = oc;
+    outCorrNormals[i] = on;
+}
+
+// scanScanElementsCS :130-188: lane x sums pixels [12x, 12x+12) in order, the 64 lanes of a wave are reduced with the
+// reference's tree (+32, +16, ... +1) and lane 0 writes the wave's 30 terms.
+__global__ __launch_bounds__(64) void k_icp_build_system(uint32_t W, uint32_t H, float* partials, const float4* input, const float4* corr,
+                                                         const float4* corrNormals, const VhIcpState* st)
+{
+    if (st->lost || st->done) return;
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const float mi = minf();
+    float acc[kIcpTerms];
+#pragma unroll
+    for (uint32_t k = 0; k < kIcpTerms; k++) acc[k] = 0.0f;
+    for (uint32_t w = 0; w < kIcpWindow; w++) {
+        const uint32_t idx = kIcpWindow * x + w;
+        if (idx % W < W && idx / W < H) {
+            const float4 tp = corr[idx], ip = input[idx], tn = corrNormals[idx];
+            if (tp.x != mi && ip.x != mi && tn.x != mi) {
+                const F3 q = mat_mul_p(st->delta, mk3(ip.x, ip.y, ip.z)); // moving point
+                const F3 pT = mk3(tp.x, tp.y, tp.z), n = mk3(tn.x, tn.y, tn.z);
+                const float weight = tn.w;
+                // buildRowSystemMatrixPlane :70-82, buildRowRHSPlane :85-88
+                const float row[6] = { n.x * q.y - n.y * q.x, n.z * q.x - n.x * q.z, n.y * q.z - n.z * q.y, -n.x, -n.y, -n.z };
+                const float b = n.x * (q.x - pT.x) + n.y * (q.y - pT.y) + n.z * (q.z - pT.z);
+                uint32_t at = 0;
+#pragma unroll
+                for (uint32_t r = 0; r < 6u; r++) {
+#pragma unroll
+                    for (uint32_t c = r; c < 6u; c++) acc[at + c - r] += weight * row[r] * row[c];
+                    at += 6u - r;
+                    acc[21u + r] += weight * row[r] * b;
+                }
+                const float dN = (pT.x - q.x) * n.x + (pT.y - q.y) * n.y + (pT.z - q.z) * n.z;
+                acc[27] += weight * dN * dN;
+                acc[28] += weight;
+                acc[29] += 1.0f;
+            }
+        }
+    }
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (uint32_t k = 0; k < kIcpTerms; k++) {
+            const float other = __shfl_down(acc[k], off);
+            if ((int)lane < off) acc[k] += other;
+        }
+    }
+    if (lane == 0u) {
+#pragma unroll
+        for (uint32_t k = 0; k < kIcpTerms; k++) partials[(size_t)blockIdx.x * kIcpTerms + k] = acc[k];
+    }
+}
+
+// One wave: reductionSystemCPU (.cpp:52-92) over the wave partials in their order, then what computeBestRigidAlignment,
+// delinearizeTransformation and align do with the system on the host (DSC/CUDACameraTrackingMultiRes.cpp:186-253,
+// 306-318).  The 6x6 symmetric system is solved through its eigen-decomposition (cyclic Jacobi, double precision):
+// x = V diag(1/l_i) V^T b with eigenvalues below 6 eps * l_max dropped, which is what Eigen's JacobiSVD::solve returns
+// for a symmetric positive semi-definite matrix; the condition number is l_max / l_min.
+__global__ __launch_bounds__(64) void k_icp_solve(VhIcpState* st, const float* partials, uint32_t nPartials, float angleThres, float distThres, float earlyOut, uint32_t lastInner)
+{
+    __shared__ float sTerms[kIcpTerms];
+    if (st->lost || st->done) return;
+    const uint32_t t = threadIdx.x;
+    if (t < kIcpTerms) {
+        float sum = 0.0f;
+        for (uint32_t k = 0; k < nPartials; k++) sum += partials[(size_t)k * kIcpTerms + t];
+        sTerms[t] = sum;
+    }
+    __syncthreads();
+    if (t != 0u) return;
+    double A[6][6], b[6];
+    {
+        uint32_t at = 0;
+        bool zero = true;
+        for (uint32_t r = 0; r < 6u; r++) {
+            for (uint32_t c = r; c < 6u; c++) {
+                A[r][c] = A[c][r] = (double)sTerms[at + c - r];
+                if (sTerms[at + c - r] != 0.0f) zero = false;
+            }
+            at += 6u - r;
+            b[r] = (double)sTerms[21u + r];
+        }
+        st->sumRegError = sTerms[27];
+        st->sumRegWeight = sTerms[28];
+        st->numCorr = (uint32_t)sTerms[29];
+        st->iterations += 1u;
+        if (zero) { st->lost = 1u; return; } // ATA.isZero(): no correspondence at all
+    }
+    // cyclic Jacobi on A (symmetric): A -> diag, V accumulates the rotations
+    double V[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0.0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < 6; k++) { // columns p, q
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; k++) { // rows p, q
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double lmax = 0.0, lmin = 1e300;
+    for (int i = 0; i < 6; i++) { const double l = fabs(A[i][i]); lmax = l > lmax ? l : lmax; lmin = l < lmin ? l : lmin; }
+    st->matrixCondition = (float)(lmax / lmin);
+    double xs[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 6; i++) {
+        const double l = fabs(A[i][i]);
+        if (l <= 6.0 * 1.1920928955078125e-7 * lmax) continue; // rank decision of JacobiSVD (threshold = diagSize * epsilon)
+        double proj = 0.0;
+        for (int k = 0; k < 6; k++) proj += V[k][i] * b[k];
+        proj /= A[i][i];
+        for (int k = 0; k < 6; k++) xs[k] += V[k][i] * proj;
+    }
+    // delinearizeTransformation :186-207: R = Rz(x0) Ry(x1) Rx(x2), t = x[3..5]; mean 0, meanStDev 1
+    const float x0 = (float)xs[0], x1 = (float)xs[1], x2 = (float)xs[2];
+    const float tx = (float)xs[3], ty = (float)xs[4], tz = (float)xs[5];
+    const float cz = cosf(x0), sz = sinf(x0), cy = cosf(x1), sy = sinf(x1), cx = cosf(x2), sx = sinf(x2);
+    float R[9] = { cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                   sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                   -sy, cy * sx, cy * cx };
+    // checkRigidTransformation :176-185: angle of the rotation (Eigen::AngleAxisf) and length of the translation
+    const float trace = R[0] + R[4] + R[8];
+    const float angle = acosf(fminf(1.0f, fmaxf(-1.0f, 0.5f * (trace - 1.0f))));
+    const float tnorm = sqrtf(tx * tx + ty * ty + tz * tz);
+    if (!(angle <= angleThres) || !(tnorm <= distThres)) { st->lost = 1u; return; }
+    // deltaTransform = t * deltaTransform
+    float M[16] = { R[0], R[1], R[2], tx, R[3], R[4], R[5], ty, R[6], R[7], R[8], tz, 0.0f, 0.0f, 0.0f, 1.0f };
+    float D[16];
+    for (int k = 0; k < 16; k++) D[k] = st->delta[k];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; k++) acc += M[4 * r + k] * D[4 * k + c];
+            st->delta[4 * r + c] = acc;
+        }
+    // align :306-318, after the last inner iteration: leave the level when the residual stops changing
+    if (lastInner) {
+        if (fabsf(st->lastError - st->sumRegError) < earlyOut) st->done = 1u;
+        st->lastError = st->sumRegError;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // streaming (DSC/CUDASceneRepChunkGrid.cu)
 // ---------------------------------------------------------------------------
 
@@ -2330,6 +2551,49 @@ int vh_erode_depth_map(float* d_output, const float* d_input, int32_t structureS
     return vh_last_launch_error();
 }
 #undef VH_IMG_LAUNCH
+
+int vh_icp_begin(VhIcpState* d_state, const float* d_deltaEstimate, vhStream_t stream)
+{
+    if (!d_state || !d_deltaEstimate) return VH_ERR_BAD_ARGUMENT;
+    k_icp_begin<<<1, 64, 0, (hipStream_t)stream>>>(d_state, d_deltaEstimate);
+    return vh_last_launch_error();
+}
+int vh_icp_begin_level(VhIcpState* d_state, vhStream_t stream)
+{
+    if (!d_state) return VH_ERR_BAD_ARGUMENT;
+    k_icp_begin_level<<<1, 64, 0, (hipStream_t)stream>>>(d_state);
+    return vh_last_launch_error();
+}
+int vh_icp_projective_correspondences(const float* d_input4, const float* d_inputNormals4, const float* d_target4, const float* d_targetNormals4,
+                                      float* d_output4, float* d_outputNormals4, uint32_t width, uint32_t height, float distThres, float normalThres,
+                                      float levelFactor, const VhIcpState* d_state, const VhDepthCameraParams* cp, vhStream_t stream)
+{
+    if (!d_input4 || !d_inputNormals4 || !d_target4 || !d_targetNormals4 || !d_output4 || !d_outputNormals4 || !d_state || !cp) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_icp_correspondences<<<cdiv(width * height, 256u), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(d_input4), reinterpret_cast<const float4*>(d_inputNormals4), reinterpret_cast<const float4*>(d_target4),
+        reinterpret_cast<const float4*>(d_targetNormals4), reinterpret_cast<float4*>(d_output4), reinterpret_cast<float4*>(d_outputNormals4), width, height,
+        distThres, normalThres, levelFactor, d_state, *cp);
+    return vh_last_launch_error();
+}
+uint32_t vh_icp_num_partials(uint32_t width, uint32_t height) { return cdiv(width * height, 64u * kIcpWindow); }
+int vh_icp_build_linear_system(uint32_t width, uint32_t height, float* d_partials, const float* d_input4, const float* d_corr4, const float* d_corrNormals4,
+                               const VhIcpState* d_state, vhStream_t stream)
+{
+    if (!d_partials || !d_input4 || !d_corr4 || !d_corrNormals4 || !d_state) return VH_ERR_BAD_ARGUMENT;
+    if (width * height == 0) return VH_OK;
+    k_icp_build_system<<<vh_icp_num_partials(width, height), 64, 0, (hipStream_t)stream>>>(
+        width, height, d_partials, reinterpret_cast<const float4*>(d_input4), reinterpret_cast<const float4*>(d_corr4),
+        reinterpret_cast<const float4*>(d_corrNormals4), d_state);
+    return vh_last_launch_error();
+}
+int vh_icp_solve(VhIcpState* d_state, const float* d_partials, uint32_t numPartials, float angleThres, float distThres, float earlyOutResidual,
+                 int lastInnerIteration, vhStream_t stream)
+{
+    if (!d_state || !d_partials) return VH_ERR_BAD_ARGUMENT;
+    k_icp_solve<<<1, 64, 0, (hipStream_t)stream>>>(d_state, d_partials, numPartials, angleThres, distThres, earlyOutResidual, lastInnerIteration ? 1u : 0u);
+    return vh_last_launch_error();
+}
 
 int vh_stream_out_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start,
                         float radius, const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_output,

@@ -601,3 +601,34 @@ class CUDARGBDSensor:
             normals=download(b.value, np.float32, W * H * 4).reshape(H, W, 4),
             intensity=download(c.value, np.float32, W * H).reshape(H, W),
         )
+
+
+class CUDACameraTrackingMultiRes:
+    """Mirror of DSC/CUDACameraTrackingMultiRes.h:17-78 over the C ABI (device pointers in, 4x4 pose out)."""
+
+    def __init__(self, imageWidth, imageHeight, levels, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        check(self.L.vh_camera_tracking_create(imageWidth, imageHeight, levels, stream, C.byref(h)), "vh_camera_tracking_create")
+        self.handle = h
+        self.state = T.IcpState()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_camera_tracking_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def applyCT(self, d_input, d_inputNormals, d_model, d_modelNormals, lastTransform, settings, deltaTransformEstimate, cameraParams):
+        """-> (4x4 float32 pose = lastTransform * delta, lost flag); the final VhIcpState is kept in self.state"""
+        out = (C.c_float * 16)()
+        lost = C.c_int(0)
+        est = f16(deltaTransformEstimate) if deltaTransformEstimate is not None else None
+        check(self.L.vh_camera_tracking_apply_ct(self.handle, d_input, d_inputNormals, d_model, d_modelNormals, f16(lastTransform), C.byref(settings),
+                                                 est, C.byref(cameraParams), out, C.byref(lost), C.byref(self.state)), "applyCT")
+        return np.array(out, dtype=np.float32).reshape(4, 4), bool(lost.value)

@@ -89,6 +89,17 @@ PROTOTYPES = {
     "vh_gauss_filter_float4_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "vh_bilateral_filter_float_map": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "vh_erode_depth_map": (C.c_int, [_VP, _VP, C.c_int32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _VP]),
+    "vh_icp_begin": (C.c_int, [_VP, _VP, _VP]),
+    "vh_icp_begin_level": (C.c_int, [_VP, _VP]),
+    "vh_icp_projective_correspondences": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _VP, P(T.DepthCameraParams), _VP]),
+    "vh_icp_num_partials": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "vh_icp_build_linear_system": (C.c_int, [C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vh_icp_solve": (C.c_int, [_VP, _VP, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_int, _VP]),
+    "vh_tracking_state_read": (C.c_int, [C.c_char_p, P(T.TrackingState)]),
+    "vh_tracking_state_parse": (C.c_int, [C.c_char_p, P(T.TrackingState)]),
+    "vh_camera_tracking_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _VP, P(_VP)]),
+    "vh_camera_tracking_destroy": (None, [_VP]),
+    "vh_camera_tracking_apply_ct": (C.c_int, [_VP, _VP, _VP, _VP, _VP, P(C.c_float), P(T.TrackingState), P(C.c_float), P(T.DepthCameraParams), P(C.c_float), P(C.c_int), P(T.IcpState)]),
     "vh_app_state_read": (C.c_int, [C.c_char_p, P(T.AppState)]),
     "vh_app_state_parse": (C.c_int, [C.c_char_p, P(T.AppState)]),
     "vh_hash_params_from_app_state": (None, [P(T.AppState), P(T.HashParams)]),

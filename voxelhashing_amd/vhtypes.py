@@ -152,6 +152,35 @@ class AppState(C.Structure):
     ]
 
 
+class TrackingState(C.Structure):
+    _fields_ = [
+        ("s_maxLevels", C.c_uint32), ("s_maxOuterIter", C.c_uint32 * 8), ("s_maxInnerIter", C.c_uint32 * 8),
+        ("s_distThres", C.c_float * 8), ("s_normalThres", C.c_float * 8), ("s_angleTransThres", C.c_float * 8),
+        ("s_distTransThres", C.c_float * 8), ("s_residualEarlyOut", C.c_float * 8), ("numLevelsFound", C.c_uint32),
+    ]
+
+
+class IcpState(C.Structure):
+    _fields_ = [
+        ("delta", C.c_float * 16), ("lastError", C.c_float), ("done", C.c_uint32), ("lost", C.c_uint32),
+        ("sumRegError", C.c_float), ("sumRegWeight", C.c_float), ("numCorr", C.c_uint32), ("matrixCondition", C.c_float),
+        ("iterations", C.c_uint32), ("pad", C.c_uint32 * 8),
+    ]
+
+
+def make_tracking_state(levels=3, outer=(8, 6, 4), inner=(1, 1, 1), dist=0.15, normal=0.97, angle_trans=1.0, dist_trans=1.0, early_out=0.01):
+    """the reference's zParametersTrackingDefault.txt"""
+    t = TrackingState()
+    t.s_maxLevels = levels
+    for i in range(levels):
+        t.s_maxOuterIter[i] = outer[i]
+        t.s_maxInnerIter[i] = inner[i]
+        t.s_distThres[i], t.s_normalThres[i] = dist, normal
+        t.s_angleTransThres[i], t.s_distTransThres[i], t.s_residualEarlyOut[i] = angle_trans, dist_trans, early_out
+    t.numLevelsFound = levels
+    return t
+
+
 class SceneOptions(C.Structure):
     _fields_ = [
         ("s_offlineProcessing", C.c_uint8),
