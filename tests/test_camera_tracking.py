@@ -15,9 +15,7 @@ import pytest
 from voxelhashing_amd import synth, vhtypes as T
 
 MINF = np.float32(-np.inf)
-# S1's big sphere sits at the centre of the orbit: the view does not change along it and no geometric tracker can see
-# the motion.  Four spheres off the centre give every direction of motion a gradient.
-TRACK_SPHERES = np.array([[-0.6, -0.3, 0.2, 0.5], [0.5, 0.2, -0.1, 0.45], [0.0, 0.45, 0.5, 0.35], [0.1, -0.5, -0.4, 0.4]], dtype=np.float64)
+TRACK_SPHERES = synth.S3_SPHERES  # S1's big sphere is centred on the orbit: no geometric tracker can see that motion
 
 
 def maps_for(O, spheres, pose, cp):

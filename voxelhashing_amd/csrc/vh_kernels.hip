@@ -1954,8 +1954,17 @@ __global__ __launch_bounds__(64) void k_icp_solve(VhIcpState* st, const float* p
     if (st->lost || st->done) return;
     const uint32_t t = threadIdx.x;
     if (t < kIcpTerms) {
+        // one term per lane, summed over the waves in their order (as reductionSystemCPU does); eight loads in flight
         float sum = 0.0f;
-        for (uint32_t k = 0; k < nPartials; k++) sum += partials[(size_t)k * kIcpTerms + t];
+        uint32_t k = 0;
+        for (; k + 8u <= nPartials; k += 8u) {
+            float v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) v[j] = partials[(size_t)(k + j) * kIcpTerms + t];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) sum += v[j];
+        }
+        for (; k < nPartials; k++) sum += partials[(size_t)k * kIcpTerms + t];
         sTerms[t] = sum;
     }
     __syncthreads();
@@ -1983,10 +1992,12 @@ __global__ __launch_bounds__(64) void k_icp_solve(VhIcpState* st, const float* p
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) V[i][j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; sweep++) {
-        double off = 0.0;
-        for (int i = 0; i < 6; i++)
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < 6; i++) {
+            diag += A[i][i] * A[i][i];
             for (int j = i + 1; j < 6; j++) off += A[i][j] * A[i][j];
-        if (off < 1e-300) break;
+        }
+        if (off <= 1e-26 * diag) break; // eigenvalues to ~1e-13 relative: far below what the float results can show
         for (int p = 0; p < 5; p++)
             for (int q = p + 1; q < 6; q++) {
                 if (fabs(A[p][q]) < 1e-300) continue;

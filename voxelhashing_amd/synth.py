@@ -18,6 +18,9 @@ SPHERE_A = np.array([[0.0, 0.0, 0.0, 1.0]], dtype=np.float64)
 # scene S2 "inside-out room": camera orbits at 0.5 m inside a sphere of r=3.0
 S2_SPHERES = np.array([[0.0, 0.0, 0.0, 3.0]], dtype=np.float64)
 S2_ORBIT_RADIUS = 0.5
+# scene S3 "tracking": four spheres off the orbit centre (S1's big sphere is centred on it: the view does not change
+# along the orbit and a geometric tracker cannot see the motion)
+S3_SPHERES = np.array([[-0.6, -0.3, 0.2, 0.5], [0.5, 0.2, -0.1, 0.45], [0.0, 0.45, 0.5, 0.35], [0.1, -0.5, -0.4, 0.4]], dtype=np.float64)
 
 # parameter sets: voxel, truncation, truncScale (truncation = 5*voxel, truncScale = 2.5*voxel)
 PARAM_SETS = {
@@ -69,6 +72,8 @@ def scene(name):
         return SPHERE_A, 0, S1_ORBIT_RADIUS
     if name == "S2":
         return S2_SPHERES, 1, S2_ORBIT_RADIUS
+    if name == "S3":
+        return S3_SPHERES, 0, S1_ORBIT_RADIUS
     raise KeyError(name)
 
 
