@@ -104,8 +104,9 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
 /* Ray-interval splatting as a compute pass: resetRayIntervalSplatCUDA / rayIntervalSplatCUDA
  * (DSC/CUDARayCastSDF.cu:88,169) + the D3D11 min/max rasterisation (DSC/DX11RayIntervalSplatting.cpp:150-220) that
  * this fork leaves disabled.  Per 8x8-pixel tile (ceil(W/8)*ceil(H/8) of them, row-major):
- *   d_tileHeads   4 words: {min, max} camera depth (float bits) of the allocated blocks the tile's rays can read,
- *                 their number, 0;
+ *   d_tileHeads   4 words: {min, max} camera depth (float bits) of the allocated blocks the tile's rays can read --
+ *                 kept only when no lists are (d_tileBlocks NULL); with lists the ray caster forms the range from the
+ *                 listed blocks --, their number, 0;
  *   d_tileBlocks  tileCapacity entries: those blocks (may be NULL: intervals only).  tileCapacity also picks the
  *                 ray caster's table size: up to VH_TILE_LIST_CAPACITY (64) small tables, above it large ones
  *                 (VH_TILE_LIST_CAPACITY_LARGE, 128).  A longer list is used as far as it fits; the blocks it could

@@ -598,8 +598,10 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
                     slot[j] = 0xffffffffu;
                     if (i < n) {
                         slot[j] = atomicAdd(&heads[t[j]].z, 1u);
-                        atomicMin(&heads[t[j]].x, lo);
-                        atomicMax(&heads[t[j]].y, hi);
+                        if (cap == 0u) { // intervals only: with lists, k_render derives the interval from the listed blocks
+                            atomicMin(&heads[t[j]].x, lo);
+                            atomicMax(&heads[t[j]].y, hi);
+                        }
                     }
                 }
 #pragma unroll
@@ -1178,7 +1180,7 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     int* tab = tileTab[threadIdx.x / kWave];
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
-    const float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y);
+    float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y); // as splatted (lists == nullptr)
     if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
     const uint32_t listed = min(head.z, min(cap, CAP));
     const bool complete = listed == head.z;
@@ -1222,6 +1224,43 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    if (cap != 0u) {
+        // With lists the splat keeps no depth range (two atomics per tile and block less): the range of the listed blocks
+        // is formed here.  Camera depth is linear in the world position, so over a (grown) box its extremes are sums of
+        // per-axis extremes; the same margins as k_interval_splat.  An overflowed list knows no range: march it all.
+        tileZmin = 0.0f;
+        tileZmax = pinf();
+        if (complete) {
+            const float vs = hp.m_virtualVoxelSize;
+            const float growLo = (GRADIENTS ? 1.75f : 1.25f) * vs, growHi = (GRADIENTS ? 0.75f : 0.25f) * vs;
+            const float* vm = rp.m_viewMatrix; // camera z of a world point: row 2
+            float zlo = pinf(), zhi = minf();
+#pragma unroll
+            for (uint32_t k = 0; k < kPerLane; k++) {
+                if (lane + k * kWave < listed) {
+                    const int b3[3] = { mine[k].x, mine[k].y, mine[k].z };
+                    float a = vm[11], b = vm[11];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        const float lo = (float)(b3[ax] * VH_SDF_BLOCK_SIZE) * vs - growLo, hi = (float)(b3[ax] * VH_SDF_BLOCK_SIZE + VH_SDF_BLOCK_SIZE) * vs + growHi;
+                        const float p = vm[8 + ax] * lo, q = vm[8 + ax] * hi;
+                        a += fminf(p, q);
+                        b += fmaxf(p, q);
+                    }
+                    const float zs = 2e-3f * fmaxf(fabsf(a), fabsf(b)) + 0.5f * vs;
+                    zlo = fminf(zlo, a - zs);
+                    zhi = fmaxf(zhi, b + zs);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                zlo = fminf(zlo, __shfl_xor(zlo, off));
+                zhi = fmaxf(zhi, __shfl_xor(zhi, off));
+            }
+            tileZmin = fmaxf(zlo, 0.0f);  // an empty list leaves {+inf, -inf}: nothing to march
+            tileZmax = zhi;
+        }
+    }
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
     const bool inImage = x < W && y < H;
     const size_t pix = (size_t)y * W + x;
