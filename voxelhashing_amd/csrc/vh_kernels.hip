@@ -1147,10 +1147,9 @@ __global__ __launch_bounds__(256) void k_render_hash(VhHashData hd, VhHashParams
     VH_STAT_STORE
 }
 
-// One wave per 8x8-pixel tile with the tile's head and block list from k_interval_splat: the wave builds its
-// block table in LDS and marches inside the tile's depth interval.  5 waves per SIMD keep all tiles of a 640x480
-// frame resident at once (4800 waves <= 5 x 4 x 256): the march is a latency chain, and a second round of waves
-// costs as much as the first.
+// One wave per 8x8-pixel tile with the tile's head and block list from k_interval_splat: the wave builds its block
+// table in LDS, forms the tile's depth interval from the listed blocks and marches inside it.  The kernel is bound by
+// VALU issue per SIMD: what counts is instructions per sample and even loads of the SIMDs.
 template <bool GRADIENTS, uint32_t CAP>
 VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCastData& rd, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
                      uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase,
