@@ -125,14 +125,17 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
 
     uint32_t iter = 0;
     while (__any(active)) {
-        bool want = active && block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask);
         // Steady state: the block exists and sits in the first slot of its bucket.  Every lane checks that for
         // its own block with ONE load (all lanes in flight together); only the rest -- new blocks and blocks
-        // further down a bucket -- goes through the serial allocBlock below.
+        // further down a bucket -- goes through the serial allocBlock below.  The reference asks "in the frustum?
+        // not streamed out?" first; the tests are independent and a block that exists needs nothing, so the cheap
+        // one goes first and the projection runs only for a block that is not where it is expected.
+        bool want = active;
         if (want) {
             const int4 q0 = load_quad(&hd.d_hash[hash_pos_fast(hm, id) * VH_HASH_BUCKET_SIZE]);
             want = !quad_matches(q0, id);
         }
+        if (want) want = block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask);
         // wave-level de-duplication of the requested block ids
         uint64_t pending = __ballot(want);
         while (pending) {
