@@ -192,7 +192,8 @@ def stage_bytes(cfg_hp, cp, n_occ, stage):
 
 
 def cpu_baseline(cfg_name, n_frames, args):
-    """the CPU oracle (single thread) on the first n_frames of the same workload"""
+    """the CPU oracle on the first n_frames of the same workload: one thread (the checker's build) and all cores
+    (the same source built with OpenMP); `value` is the faster, all-core figure"""
     from oracle import oracle as O
     from voxelhashing_amd import synth, vhtypes as T
     cfg = dict(synth.CONFIGS[cfg_name])
@@ -201,18 +202,31 @@ def cpu_baseline(cfg_name, n_frames, args):
     hp, cp, rp = synth.config_params(cfg)
     opt = T.make_scene_options(offline=args.offline, gc=not args.no_gc, starve=15)
     spheres, inside, radius = synth.scene(cfg["scene"])
-    sc = O.OracleScene(hp, cp, rp, opt)
     poses = [synth.orbit_pose(k, 1000, radius, 0.0) for k in range(n_frames)]
     inputs = [O.synth_frame(spheres, inside, p, cp) for p in poses]
-    t0 = time.perf_counter()
-    for k in range(n_frames):
-        if k > 0:
-            sc.render(poses[k - 1])
-        sc.integrate(poses[k], inputs[k][0], inputs[k][1])
-    dt = time.perf_counter() - t0
-    sc.close()
-    return dict(value=n_frames / dt, unit="frames/s", cores=1, kind="port",
-                sample=f"first {n_frames} frames of {cfg_name} ({cfg['scene']}), oracle/libvh_oracle.so, 1 thread, {dt:.1f} s")
+
+    def timed(omp):
+        sc = O.OracleScene(hp, cp, rp, opt, omp=omp)
+        t0 = time.perf_counter()
+        for k in range(n_frames):
+            if k > 0:
+                sc.render(poses[k - 1])
+            sc.integrate(poses[k], inputs[k][0], inputs[k][1])
+        dt = time.perf_counter() - t0
+        blocks = sc.hp.m_numOccupiedBlocks
+        sc.close()
+        return dt, blocks
+
+    dt1, blocks1 = timed(False)
+    # a GPU box gives one GPU's share of the host (16 cores): do not let OpenMP start a thread per host core
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0))))))
+    cores = int(O.lib(omp=True).vho_num_threads())
+    dtn, blocksn = timed(True)
+    if blocks1 != blocksn:
+        raise RuntimeError(f"all-core baseline diverged from the checker: {blocksn} vs {blocks1} blocks")
+    return dict(value=n_frames / dtn, unit="frames/s", cores=cores, kind="port", single_thread=n_frames / dt1,
+                sample=f"first {n_frames} frames of {cfg_name} ({cfg['scene']}): oracle/libvh_oracle_omp.so on {cores} threads "
+                       f"{dtn:.1f} s; oracle/libvh_oracle.so on 1 thread {dt1:.1f} s")
 
 
 def main():

@@ -13,21 +13,22 @@ import numpy as np
 from voxelhashing_amd import vhtypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def lib():
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = os.path.join(_HERE, "libvh_oracle.so")
+def lib(omp=False):
+    """the checker (serial build); omp=True: the same source built with OpenMP, bench.py's all-core CPU baseline"""
+    if omp in _LIBS:
+        return _LIBS[omp]
+    path = os.path.join(_HERE, "libvh_oracle_omp.so" if omp else "libvh_oracle.so")
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)
+    L.vho_num_threads.restype = C.c_int
     P = C.POINTER
     L.vho_hash_data_alloc.argtypes = [P(T.HashData), P(T.HashParams)]
     L.vho_hash_data_alloc.restype = C.c_int
@@ -85,7 +86,7 @@ def lib():
     L.vho_raycast_render.argtypes = [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams),
                                      P(T.RayCastParams), P(C.c_float)]
     L.vho_synth_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_float), P(T.DepthCameraParams), C.c_void_p, C.c_void_p]
-    _LIB = L
+    _LIBS[omp] = L
     return L
 
 
@@ -133,8 +134,8 @@ def compute_normals(depth4):
 class OracleScene:
     """Oracle twin of CUDASceneRepHashSDF + CUDARayCastSDF on host memory."""
 
-    def __init__(self, hash_params, cam_params, ray_params=None, options=None):
-        self.L = lib()
+    def __init__(self, hash_params, cam_params, ray_params=None, options=None, omp=False):
+        self.L = lib(omp)
         self.hp = _copy_struct(hash_params)
         self.cp = _copy_struct(cam_params)
         self.rp = _copy_struct(ray_params) if ray_params is not None else T.make_raycast_params(self.hp, self.cp)

@@ -16,6 +16,11 @@
  * reproduced (hard part 4): see vho_insert_hash_entry and
  * vho_stream_out_pass1.
  *
+ * The `#pragma omp` lines and `#ifdef _OPENMP` sections are inert in the
+ * checker (libvh_oracle.so, built without -fopenmp).  libvh_oracle_omp.so, the
+ * same file built with -fopenmp, is bench.py's all-core CPU baseline
+ * (SURVEY.md 8(d)); a test holds it to the serial build's results.
+ *
  * PARITY UNPINNED (see vh_oracle.h).
  */
 #include "vh_oracle.h"
@@ -23,6 +28,19 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP /* only libvh_oracle_omp.so, the bench's all-core CPU baseline; the checker is built without */
+#include <omp.h>
+#endif
+
+/* threads the parallel sections use: 1 in the checker's build */
+int vho_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------- */
 /* small vector helpers                                                      */
@@ -548,6 +566,7 @@ void vho_reset(VhHashData* hd, const VhHashParams* hp)
 /* resetHashBucketMutexCUDA :109-120 */
 void vho_reset_bucket_mutex(VhHashData* hd, const VhHashParams* hp)
 {
+#pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < hp->m_hashNumBuckets; i++) hd->d_hashBucketMutex[i] = VH_FREE_ENTRY;
 }
 
@@ -573,21 +592,34 @@ static inline int block_streamed_out(const VhHashParams* hp, i3 blk, const uint3
     return (bitMask[index / 32] & (0x1u << (index % 32))) != 0;
 }
 
-/* allocKernel :158-243, threads in raster order */
-void vho_alloc(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
-               const VhDepthCameraParams* cp, const uint32_t* bitMask)
+/* Blocks a pass of the multi-threaded baseline build wants and does not find (see vho_alloc). */
+typedef struct { i3* v; size_t n, cap; } BlockList;
+
+static void block_list_push(BlockList* l, i3 b)
+{
+    if (l->n == l->cap) {
+        l->cap = l->cap ? 2 * l->cap : 256;
+        l->v = (i3*)realloc(l->v, l->cap * sizeof(i3));
+        if (!l->v) abort();
+    }
+    l->v[l->n++] = b;
+}
+
+/* allocKernel :158-243, one thread = one pixel.  `missing` == NULL: allocate on the spot (the restatement proper).
+ * Otherwise the table is only read and the blocks that are wanted and absent are listed. */
+static void alloc_pixel(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+                        const VhDepthCameraParams* cp, const uint32_t* bitMask, uint32_t x, uint32_t y, BlockList* missing)
 {
     const float vs = hp->m_virtualVoxelSize;
-    for (uint32_t y = 0; y < cp->m_imageHeight; y++)
-    for (uint32_t x = 0; x < cp->m_imageWidth; x++) {
+    {
         float d = cam->d_depthData[y * cp->m_imageWidth + x];
-        if (d == MINF || d == 0.0f) continue;
-        if (d >= hp->m_maxIntegrationDistance) continue;
+        if (d == MINF || d == 0.0f) return;
+        if (d >= hp->m_maxIntegrationDistance) return;
 
         float t = get_truncation(hp, d);
         float minDepth = fminf(hp->m_maxIntegrationDistance, d - t);
         float maxDepth = fminf(hp->m_maxIntegrationDistance, d + t);
-        if (minDepth >= maxDepth) continue;
+        if (minDepth >= maxDepth) return;
 
         f3 rayMin = mat_mul_p(hp->m_rigidTransform, depth_to_skeleton(cp, x, y, minDepth));
         f3 rayMax = mat_mul_p(hp->m_rigidTransform, depth_to_skeleton(cp, x, y, maxDepth));
@@ -618,7 +650,10 @@ void vho_alloc(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* 
 
         uint32_t iter = 0;
         while (iter < 1024) {
-            if (block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask)) alloc_block(hd, hp, id);
+            if (block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask)) {
+                if (!missing) alloc_block(hd, hp, id);
+                else if (get_hash_entry_for_block(hd, hp, id).ptr == VH_FREE_ENTRY) block_list_push(missing, id);
+            }
 
             if (tMax.x < tMax.y && tMax.x < tMax.z) {
                 id.x = f2i((float)id.x + step.x);
@@ -638,12 +673,69 @@ void vho_alloc(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* 
     }
 }
 
+/* Threads in raster order.  Built with OpenMP (the bench's all-core CPU baseline, never the checker) the pass has
+ * two phases: every pixel walks its ray against the unchanged table and lists the blocks it misses, rows split into
+ * contiguous bands; then the lists are allocated serially in band order -- the raster order of the serial pass,
+ * since allocBlock on a block that exists changes nothing -- so both builds leave the same table. */
+void vho_alloc(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
+               const VhDepthCameraParams* cp, const uint32_t* bitMask)
+{
+#ifdef _OPENMP
+    const int nt = omp_get_max_threads();
+    BlockList* lists = (BlockList*)calloc((size_t)nt, sizeof(BlockList));
+    if (!lists) abort();
+#pragma omp parallel num_threads(nt)
+    {
+        const int tid = omp_get_thread_num();
+        const uint32_t H = cp->m_imageHeight;
+        const uint32_t y0 = (uint32_t)((uint64_t)H * (uint32_t)tid / (uint32_t)nt), y1 = (uint32_t)((uint64_t)H * ((uint32_t)tid + 1) / (uint32_t)nt);
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = 0; x < cp->m_imageWidth; x++) alloc_pixel(hd, hp, cam, cp, bitMask, x, y, &lists[tid]);
+    }
+    for (int t = 0; t < nt; t++) {
+        for (size_t k = 0; k < lists[t].n; k++) alloc_block(hd, hp, lists[t].v[k]);
+        free(lists[t].v);
+    }
+    free(lists);
+#else
+    for (uint32_t y = 0; y < cp->m_imageHeight; y++)
+        for (uint32_t x = 0; x < cp->m_imageWidth; x++) alloc_pixel(hd, hp, cam, cp, bitMask, x, y, NULL);
+#endif
+}
+
 /* compactifyHashAllInOneCUDA :361-377 (kernel :317-359; output order is
  * arbitrary in the reference, entry order here). */
 uint32_t vho_compactify(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp)
 {
     const uint32_t ne = num_entries(hp);
     int32_t count = 0;
+#ifdef _OPENMP
+    /* all-core baseline build: contiguous slices of the table, counted then copied, so the output keeps entry order */
+    const int nt = omp_get_max_threads();
+    int32_t* first = (int32_t*)calloc((size_t)nt + 1, sizeof(int32_t));
+    if (!first) abort();
+#pragma omp parallel num_threads(nt)
+    {
+        const int tid = omp_get_thread_num();
+        const uint32_t i0 = (uint32_t)((uint64_t)ne * (uint32_t)tid / (uint32_t)nt), i1 = (uint32_t)((uint64_t)ne * ((uint32_t)tid + 1) / (uint32_t)nt);
+        int32_t n = 0;
+        for (uint32_t idx = i0; idx < i1; idx++) {
+            const VhHashEntry* e = &hd->d_hash[idx];
+            if (e->ptr != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(e->pos[0], e->pos[1], e->pos[2]))) n++;
+        }
+        first[tid + 1] = n;
+#pragma omp barrier
+#pragma omp single
+        for (int t = 0; t < nt; t++) first[t + 1] += first[t];
+        int32_t at = first[tid];
+        for (uint32_t idx = i0; idx < i1 && at < first[tid + 1]; idx++) {
+            const VhHashEntry* e = &hd->d_hash[idx];
+            if (e->ptr != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(e->pos[0], e->pos[1], e->pos[2]))) copy_entry(&hd->d_hashCompactified[at++], e);
+        }
+    }
+    count = first[nt];
+    free(first);
+#else
     for (uint32_t idx = 0; idx < ne; idx++) {
         const VhHashEntry* e = &hd->d_hash[idx];
         if (e->ptr != VH_FREE_ENTRY) {
@@ -653,6 +745,7 @@ uint32_t vho_compactify(VhHashData* hd, const VhHashParams* hp, const VhDepthCam
             }
         }
     }
+#endif
     hd->d_hashCompactifiedCounter[0] = count;
     return (uint32_t)count;
 }
@@ -661,6 +754,7 @@ uint32_t vho_compactify(VhHashData* hd, const VhHashParams* hp, const VhDepthCam
 void vho_integrate(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
                    const VhDepthCameraParams* cp)
 {
+#pragma omp parallel for schedule(dynamic, 4) /* blocks are independent; the pragma is inert in the checker's build */
     for (uint32_t b = 0; b < hp->m_numOccupiedBlocks; b++) {
         const VhHashEntry entry = hd->d_hashCompactified[b];
         i3 base = block_to_vvp(mki3(entry.pos[0], entry.pos[1], entry.pos[2]));
@@ -710,6 +804,7 @@ void vho_integrate(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraDa
 /* starveVoxelsKernel :512-521 */
 void vho_starve(VhHashData* hd, const VhHashParams* hp)
 {
+#pragma omp parallel for schedule(dynamic, 16)
     for (uint32_t b = 0; b < hp->m_numOccupiedBlocks; b++) {
         const VhHashEntry* e = &hd->d_hashCompactified[b];
         for (uint32_t i = 0; i < VH_SDF_BLOCK_VOXELS; i++) {
@@ -723,6 +818,7 @@ void vho_starve(VhHashData* hd, const VhHashParams* hp)
 /* garbageCollectIdentifyKernel :543-590 (min/max tree: order-independent) */
 void vho_gc_identify(VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp)
 {
+#pragma omp parallel for schedule(dynamic, 16)
     for (uint32_t b = 0; b < hp->m_numOccupiedBlocks; b++) {
         const VhHashEntry* e = &hd->d_hashCompactified[b];
         float minSDF = PINF;
@@ -831,6 +927,7 @@ static f3 gradient_for_point(const VhHashData* hd, const VhHashParams* hp, f3 po
 void vho_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd,
                 const VhDepthCameraParams* cp, const VhRayCastParams* rp)
 {
+#pragma omp parallel for schedule(dynamic, 2) /* rays are independent */
     for (uint32_t y = 0; y < rp->m_height; y++)
     for (uint32_t x = 0; x < rp->m_width; x++) {
         size_t pix = (size_t)y * rp->m_width + x;
@@ -901,6 +998,7 @@ void vho_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastDat
 /* computeNormalsDevice, DSC/CameraUtil.cu:669-697 */
 void vho_compute_normals(float* out4, const float* in4, uint32_t width, uint32_t height)
 {
+#pragma omp parallel for schedule(static)
     for (uint32_t y = 0; y < height; y++)
     for (uint32_t x = 0; x < width; x++) {
         float* o = &out4[4 * ((size_t)y * width + x)];
