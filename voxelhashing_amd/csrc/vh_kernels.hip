@@ -86,9 +86,6 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
     // the compaction that follows needs its counter at zero: cleared here instead of by a separate memset
     if (blockIdx.x == 0 && threadIdx.x == 0) hd.d_hashCompactifiedCounter[0] = 0;
     if (tile >= tilesX * tilesY) return; // wave-uniform
-#if VH_ALLOC_VARIANT == 2
-    return;
-#endif
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
     const float vs = hp.m_virtualVoxelSize;
 
@@ -126,10 +123,6 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
     if (rayDir.z == 0.0f) { tMax.z = pinf(); tDelta.z = pinf(); }
     if (boundaryPos.z - rayMin.z == 0.0f) { tMax.z = pinf(); tDelta.z = pinf(); }
 
-#if VH_ALLOC_VARIANT == 1
-    if (active && id.x == 12345678 && tMax.x == 3.0f && tDelta.y == 4.0f && tMax.z == tDelta.z && idBound.y == id.z) hd.d_hashCompactifiedCounter[1] = 1;
-    return;
-#endif
     uint32_t iter = 0;
     while (__any(active)) {
         // Steady state: the block exists and sits in the first slot of its bucket.  Every lane checks that for
@@ -138,14 +131,10 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
         // not streamed out?" first; the tests are independent and a block that exists needs nothing, so the cheap
         // one goes first and the projection runs only for a block that is not where it is expected.
         bool want = active;
-#if VH_ALLOC_VARIANT == 3
-        want = active && id.x == 12345678;
-#else
         if (want) {
             const int4 q0 = load_quad(&hd.d_hash[hash_pos_fast(hm, id) * VH_HASH_BUCKET_SIZE]);
             want = !quad_matches(q0, id);
         }
-#endif
         if (want) want = block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask);
         // wave-level de-duplication of the requested block ids
         uint64_t pending = __ballot(want);
