@@ -392,6 +392,70 @@ private:
 
 
 // ---------------------------------------------------------------------------
+// Recorded sequences: ml::SensorData, the `.sens` container (DSC/sensorData/sensorData.h), and
+// SensorDataReader (DSC/SensorDataReader.{h,cpp}).  Host side; see voxelhashing_amd/csrc/vh_sensor_data.cpp.
+namespace vh {
+
+class SensorData {
+public:
+    static const uint32_t kVersion = 4; // M_SENSOR_DATA_VERSION, sensorData.h:607
+    enum COMPRESSION_TYPE_COLOR { TYPE_RAW = 0, TYPE_PNG = 1, TYPE_JPEG = 2 };                     // :217-221
+    enum COMPRESSION_TYPE_DEPTH { TYPE_RAW_USHORT = 0, TYPE_ZLIB_USHORT = 1, TYPE_OCCI_USHORT = 2 }; // :222-226
+    struct RGBDFrame { // :229-551
+        std::vector<uint8_t> m_colorCompressed, m_depthCompressed;
+        uint64_t m_timeStampColor = 0, m_timeStampDepth = 0; // microseconds by convention
+        mat4f m_cameraToWorld;
+    };
+    struct IMUFrame { // :553-605: 15 doubles and a time stamp, 128 bytes in the file
+        double rotationRate[3], acceleration[3], magneticField[3], attitude[3], gravity[3];
+        uint64_t timeStamp;
+    };
+
+    SensorData();
+    static mat4f makeIntrinsicMatrix(float fx, float fy, float mx, float my);
+    void loadFromFile(const std::string& filename); // throws vh::Error: VH_ERR_IO, VH_ERR_VERSION_MISMATCH
+    void saveToFile(const std::string& filename) const;
+    // compresses with the file's compression types: depth raw / zlib; colour raw only (NULL = frame without colour)
+    void addFrame(const uint8_t* colorRGB, const uint16_t* depth, const mat4f& cameraToWorld = mat4f::identity(),
+                  uint64_t timeStampColor = 0, uint64_t timeStampDepth = 0);
+    void decompressDepth(size_t frameIdx, uint16_t* out) const;   // depthWidth*depthHeight samples
+    void decompressColor(size_t frameIdx, uint8_t* outRGB) const; // colorWidth*colorHeight*3 bytes; raw, PNG, baseline JPEG
+
+    uint32_t m_versionNumber;
+    std::string m_sensorName;
+    mat4f m_colorIntrinsic, m_colorExtrinsic, m_depthIntrinsic, m_depthExtrinsic; // CalibrationData :150-215
+    int32_t m_colorCompressionType, m_depthCompressionType;
+    uint32_t m_colorWidth, m_colorHeight, m_depthWidth, m_depthHeight;
+    float m_depthShift; // depth in metres = sample / m_depthShift
+    std::vector<RGBDFrame> m_frames;
+    std::vector<IMUFrame> m_IMUFrames;
+};
+
+class SensorDataReader { // the RGBDSensor the frame loop polls when s_sensorIdx selects a recorded sequence
+public:
+    SensorDataReader();
+    void createFirstConnected(const std::string& filename);
+    bool processDepth(); // decodes the next frame; false once the sequence is complete
+    const float* getDepthFloat() const { return m_depthFloat.data(); }    // metres, 0 = no measurement
+    const uint8_t* getColorRGBX() const { return m_colorRGBX.data(); }    // {r, g, b, 1}
+    mat4f getRigidTransform(int offset = 0) const;                        // recorded pose of the frame last decoded
+    unsigned int getNumFrames() const { return m_numFrames; }
+    unsigned int getCurrFrame() const { return m_currFrame; }
+    bool hasColorData() const { return m_bHasColorData; }
+    const SensorData& getSensorData() const;
+
+private:
+    std::unique_ptr<SensorData> m_sensorData;
+    std::vector<float> m_depthFloat;
+    std::vector<uint8_t> m_colorRGBX, m_colorRGB;
+    std::vector<uint16_t> m_depthShorts;
+    unsigned int m_numFrames, m_currFrame;
+    bool m_bHasColorData;
+};
+
+} // namespace vh
+
+// ---------------------------------------------------------------------------
 // CUDARGBDSensor over CUDARGBDAdapter (DSC/CUDARGBDSensor.{h,cpp}, DSC/CUDARGBDAdapter.{h,cpp}): the image path from
 // a sensor frame (float depth in metres + RGBX bytes, host memory, as RGBDSensor::getDepthFloat / getColorRGBX
 // deliver them) to the DepthCameraData that integrate() consumes, plus the camera-space and normal maps tracking uses.

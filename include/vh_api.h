@@ -297,6 +297,38 @@ int vh_rgbd_sensor_get_depth_camera_params(VhRGBDSensor* s, VhDepthCameraParams*
 /* device maps at adapter resolution: {camera space float4, normals float4, intensity float} */
 int vh_rgbd_sensor_get_maps(VhRGBDSensor* s, float** d_cameraSpace4, float** d_normals4, float** d_intensity);
 
+/* ---- recorded sequences: the `.sens` container and its reader.
+ *   VhSensorData        ml::SensorData (load / save / frames)          DSC/sensorData/sensorData.h:608-830
+ *   VhSensorDataReader  SensorDataReader (the sensor the loop polls)    DSC/SensorDataReader.cpp:39-179
+ * Host side only; depth raw / zlib, colour raw / PNG / baseline JPEG are decoded (see vh_sensor_data.cpp). */
+typedef struct VhSensorData VhSensorData;
+int vh_sensor_data_create(const VhSensorDataInfo* header, VhSensorData** out); /* empty sequence with this header */
+int vh_sensor_data_load(const char* filename, VhSensorData** out);             /* loadFromFile :789-830 */
+void vh_sensor_data_destroy(VhSensorData* s);
+int vh_sensor_data_save(const VhSensorData* s, const char* filename);          /* saveToFile :756-787 */
+int vh_sensor_data_info(const VhSensorData* s, VhSensorDataInfo* out);
+/* addFrame :657-667.  colorRGB (3 bytes / pixel) or depth may be NULL; stored with the header's compression types
+ * (depth raw / zlib, colour raw). */
+int vh_sensor_data_add_frame(VhSensorData* s, const uint8_t* colorRGB, const uint16_t* depth, const float cameraToWorld[16],
+                             uint64_t timeStampColor, uint64_t timeStampDepth);
+/* stores an already compressed colour frame (PNG / JPEG bytes as another tool produced them) with the frame's depth */
+int vh_sensor_data_add_frame_compressed(VhSensorData* s, const uint8_t* colorBytes, uint64_t numColorBytes, const uint16_t* depth,
+                                        const float cameraToWorld[16], uint64_t timeStampColor, uint64_t timeStampDepth);
+int vh_sensor_data_add_imu_frame(VhSensorData* s, const double values15[15], uint64_t timeStamp);
+/* decompressDepthAlloc / decompressColorAlloc :687-705 and the frame's pose and time stamps; any output may be NULL */
+int vh_sensor_data_get_frame(const VhSensorData* s, uint64_t frameIdx, uint16_t* depth, uint8_t* colorRGB, float cameraToWorld[16],
+                             uint64_t timeStamps[2]);
+
+typedef struct VhSensorDataReader VhSensorDataReader;
+int vh_sensor_data_reader_create(const char* filename, VhSensorDataReader** out); /* createFirstConnected */
+void vh_sensor_data_reader_destroy(VhSensorDataReader* r);
+int vh_sensor_data_reader_info(const VhSensorDataReader* r, VhSensorDataInfo* out);
+/* processDepth: decodes the next frame.  *gotFrame = 0 once the sequence is complete.  The pointers stay valid until
+ * the next call: depth in metres (depthWidth*depthHeight floats), colour {r, g, b, 1} (colorWidth*colorHeight*4). */
+int vh_sensor_data_reader_process_depth(VhSensorDataReader* r, int* gotFrame, const float** depthFloat, const uint8_t** colorRGBX);
+int vh_sensor_data_reader_get_rigid_transform(const VhSensorDataReader* r, int offset, float out[16]); /* getRigidTransform :172-179 */
+int vh_sensor_data_reader_get_curr_frame(const VhSensorDataReader* r, uint32_t* currFrame, uint32_t* numFrames);
+
 /* ---- projective ICP camera tracking.  Launcher level: the steps of one alignment, each a kernel
  * that reads and updates a VhIcpState in device memory (a step returns at once when the state says "lost" or "level
  * done"), so that a whole multi-resolution solve runs without a host round trip.

@@ -257,6 +257,19 @@ typedef struct VhTrackingState {
     uint32_t numLevelsFound; /* how many levels of s_maxOuterIter the file held */
 } VhTrackingState;
 
+/* Header of a recorded sequence (`.sens`, ml::SensorData, DSC/sensorData/sensorData.h:608-830): what
+ * SensorDataReader::createFirstConnected hands to RGBDSensor::init and the intrinsics / extrinsics setters. */
+typedef struct VhSensorDataInfo {
+    uint32_t m_versionNumber;
+    int32_t m_colorCompressionType; /* 0 raw, 1 PNG, 2 JPEG */
+    int32_t m_depthCompressionType; /* 0 raw u16, 1 zlib u16, 2 uplink (refused) */
+    uint32_t m_colorWidth, m_colorHeight, m_depthWidth, m_depthHeight;
+    float m_depthShift; /* metres = sample / m_depthShift */
+    uint64_t m_numFrames, m_numIMUFrames;
+    float m_colorIntrinsic[16], m_colorExtrinsic[16], m_depthIntrinsic[16], m_depthExtrinsic[16];
+    char m_sensorName[64];
+} VhSensorDataInfo;
+
 /* Device-resident state of one camera-tracking solve (vh_icp_*): the delta transform being refined and what the
  * reference keeps in LinearSystemConfidence (DSC/ICPErrorLog.h:16-58). */
 typedef struct VhIcpState {

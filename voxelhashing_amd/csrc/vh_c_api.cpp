@@ -12,6 +12,8 @@ struct VhSceneRep { CUDASceneRepHashSDF impl; VhSceneRep(const HashParams& p, co
 struct VhRayCast { CUDARayCastSDF impl; VhRayCast(const RayCastParams& p, vhStream_t s) : impl(p, s) {} };
 struct VhMarchingCubes { CUDAMarchingCubesHashSDF impl; VhMarchingCubes(const MarchingCubesParams& p, vhStream_t s) : impl(p, s) {} };
 struct VhRGBDSensor { CUDARGBDSensor impl; VhRGBDSensor(const CUDARGBDSensor::Config& c, vhStream_t s) : impl(c, s) {} };
+struct VhSensorData { vh::SensorData impl; };
+struct VhSensorDataReader { vh::SensorDataReader impl; };
 struct VhCameraTracking { CUDACameraTrackingMultiRes impl; VhCameraTracking(unsigned int w, unsigned int h, unsigned int l, vhStream_t s) : impl(w, h, l, s) {} };
 struct VhChunkGrid {
     CUDASceneRepChunkGrid impl;
@@ -372,6 +374,140 @@ int vh_marching_cubes_save_mesh(VhMarchingCubes* mc, const char* filename, const
         if (transform) { const vh::mat4f t = toMat(transform); mc->impl.saveMesh(filename, &t, overwriteExistingFile != 0); }
         else mc->impl.saveMesh(filename, nullptr, overwriteExistingFile != 0);
     });
+}
+
+// ---- SensorData / SensorDataReader ------------------------------------------------
+
+namespace {
+void fillInfo(const vh::SensorData& d, VhSensorDataInfo* out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->m_versionNumber = d.m_versionNumber;
+    out->m_colorCompressionType = d.m_colorCompressionType; out->m_depthCompressionType = d.m_depthCompressionType;
+    out->m_colorWidth = d.m_colorWidth; out->m_colorHeight = d.m_colorHeight;
+    out->m_depthWidth = d.m_depthWidth; out->m_depthHeight = d.m_depthHeight;
+    out->m_depthShift = d.m_depthShift;
+    out->m_numFrames = d.m_frames.size(); out->m_numIMUFrames = d.m_IMUFrames.size();
+    std::memcpy(out->m_colorIntrinsic, d.m_colorIntrinsic.m, 64); std::memcpy(out->m_colorExtrinsic, d.m_colorExtrinsic.m, 64);
+    std::memcpy(out->m_depthIntrinsic, d.m_depthIntrinsic.m, 64); std::memcpy(out->m_depthExtrinsic, d.m_depthExtrinsic.m, 64);
+    std::strncpy(out->m_sensorName, d.m_sensorName.c_str(), sizeof(out->m_sensorName) - 1);
+}
+} // namespace
+
+int vh_sensor_data_create(const VhSensorDataInfo* h, VhSensorData** out)
+{
+    if (!h || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] {
+        std::unique_ptr<VhSensorData> s(new VhSensorData);
+        vh::SensorData& d = s->impl;
+        if (h->m_versionNumber != 0 && h->m_versionNumber != vh::SensorData::kVersion) throw vh::Error(VH_ERR_VERSION_MISMATCH, "only version 4 sequences can be written");
+        d.m_sensorName = std::string(h->m_sensorName, strnlen(h->m_sensorName, sizeof(h->m_sensorName)));
+        d.m_colorCompressionType = h->m_colorCompressionType; d.m_depthCompressionType = h->m_depthCompressionType;
+        if (d.m_colorCompressionType < 0 || d.m_colorCompressionType > 2 || d.m_depthCompressionType < 0 || d.m_depthCompressionType > 1)
+            throw vh::Error(VH_ERR_BAD_ARGUMENT, "compression type not supported for writing");
+        d.m_colorWidth = h->m_colorWidth; d.m_colorHeight = h->m_colorHeight; d.m_depthWidth = h->m_depthWidth; d.m_depthHeight = h->m_depthHeight;
+        d.m_depthShift = h->m_depthShift;
+        d.m_colorIntrinsic = toMat(h->m_colorIntrinsic); d.m_colorExtrinsic = toMat(h->m_colorExtrinsic);
+        d.m_depthIntrinsic = toMat(h->m_depthIntrinsic); d.m_depthExtrinsic = toMat(h->m_depthExtrinsic);
+        *out = s.release();
+    });
+}
+int vh_sensor_data_load(const char* filename, VhSensorData** out)
+{
+    if (!filename || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] {
+        std::unique_ptr<VhSensorData> s(new VhSensorData);
+        s->impl.loadFromFile(filename);
+        *out = s.release();
+    });
+}
+void vh_sensor_data_destroy(VhSensorData* s) { delete s; }
+int vh_sensor_data_save(const VhSensorData* s, const char* filename)
+{
+    if (!s || !filename) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.saveToFile(filename); });
+}
+int vh_sensor_data_info(const VhSensorData* s, VhSensorDataInfo* out)
+{
+    if (!s || !out) return VH_ERR_BAD_ARGUMENT;
+    fillInfo(s->impl, out);
+    return VH_OK;
+}
+int vh_sensor_data_add_frame(VhSensorData* s, const uint8_t* colorRGB, const uint16_t* depth, const float cameraToWorld[16], uint64_t tsColor, uint64_t tsDepth)
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.addFrame(colorRGB, depth, cameraToWorld ? toMat(cameraToWorld) : vh::mat4f::identity(), tsColor, tsDepth); });
+}
+int vh_sensor_data_add_frame_compressed(VhSensorData* s, const uint8_t* colorBytes, uint64_t numColorBytes, const uint16_t* depth,
+                                        const float cameraToWorld[16], uint64_t tsColor, uint64_t tsDepth)
+{
+    if (!s || (!colorBytes && numColorBytes)) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        s->impl.addFrame(nullptr, depth, cameraToWorld ? toMat(cameraToWorld) : vh::mat4f::identity(), tsColor, tsDepth);
+        s->impl.m_frames.back().m_colorCompressed.assign(colorBytes, colorBytes + numColorBytes);
+    });
+}
+int vh_sensor_data_add_imu_frame(VhSensorData* s, const double v[15], uint64_t timeStamp)
+{
+    if (!s || !v) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        vh::SensorData::IMUFrame f;
+        std::memcpy(&f, v, 15 * sizeof(double));
+        f.timeStamp = timeStamp;
+        s->impl.m_IMUFrames.push_back(f);
+    });
+}
+int vh_sensor_data_get_frame(const VhSensorData* s, uint64_t idx, uint16_t* depth, uint8_t* colorRGB, float cameraToWorld[16], uint64_t timeStamps[2])
+{
+    if (!s) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        if (idx >= s->impl.m_frames.size()) throw vh::Error(VH_ERR_BAD_ARGUMENT, "out of bounds");
+        const vh::SensorData::RGBDFrame& f = s->impl.m_frames[(size_t)idx];
+        if (depth) s->impl.decompressDepth((size_t)idx, depth);
+        if (colorRGB) s->impl.decompressColor((size_t)idx, colorRGB);
+        if (cameraToWorld) std::memcpy(cameraToWorld, f.m_cameraToWorld.m, 64);
+        if (timeStamps) { timeStamps[0] = f.m_timeStampColor; timeStamps[1] = f.m_timeStampDepth; }
+    });
+}
+
+int vh_sensor_data_reader_create(const char* filename, VhSensorDataReader** out)
+{
+    if (!filename || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] {
+        std::unique_ptr<VhSensorDataReader> r(new VhSensorDataReader);
+        r->impl.createFirstConnected(filename);
+        *out = r.release();
+    });
+}
+void vh_sensor_data_reader_destroy(VhSensorDataReader* r) { delete r; }
+int vh_sensor_data_reader_info(const VhSensorDataReader* r, VhSensorDataInfo* out)
+{
+    if (!r || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { fillInfo(r->impl.getSensorData(), out); });
+}
+int vh_sensor_data_reader_process_depth(VhSensorDataReader* r, int* gotFrame, const float** depthFloat, const uint8_t** colorRGBX)
+{
+    if (!r || !gotFrame) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] {
+        *gotFrame = r->impl.processDepth() ? 1 : 0;
+        if (depthFloat) *depthFloat = r->impl.getDepthFloat();
+        if (colorRGBX) *colorRGBX = r->impl.getColorRGBX();
+    });
+}
+int vh_sensor_data_reader_get_rigid_transform(const VhSensorDataReader* r, int offset, float out[16])
+{
+    if (!r || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { std::memcpy(out, r->impl.getRigidTransform(offset).m, 64); });
+}
+int vh_sensor_data_reader_get_curr_frame(const VhSensorDataReader* r, uint32_t* currFrame, uint32_t* numFrames)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    if (currFrame) *currFrame = r->impl.getCurrFrame();
+    if (numFrames) *numFrames = r->impl.getNumFrames();
+    return VH_OK;
 }
 
 // ---- CUDARGBDSensor ---------------------------------------------------------------

@@ -106,6 +106,21 @@ PROTOTYPES = {
     "vh_raycast_params_from_app_state": (None, [P(T.AppState), P(C.c_float), P(C.c_float), P(T.RayCastParams)]),
     "vh_marching_cubes_params_from_app_state": (None, [P(T.AppState), P(T.MarchingCubesParams)]),
     "vh_scene_options_from_app_state": (None, [P(T.AppState), P(T.SceneOptions)]),
+    "vh_sensor_data_create": (C.c_int, [P(T.SensorDataInfo), P(_VP)]),
+    "vh_sensor_data_load": (C.c_int, [C.c_char_p, P(_VP)]),
+    "vh_sensor_data_destroy": (None, [_VP]),
+    "vh_sensor_data_save": (C.c_int, [_VP, C.c_char_p]),
+    "vh_sensor_data_info": (C.c_int, [_VP, P(T.SensorDataInfo)]),
+    "vh_sensor_data_add_frame": (C.c_int, [_VP, _VP, _VP, P(C.c_float), C.c_uint64, C.c_uint64]),
+    "vh_sensor_data_add_frame_compressed": (C.c_int, [_VP, _VP, C.c_uint64, _VP, P(C.c_float), C.c_uint64, C.c_uint64]),
+    "vh_sensor_data_add_imu_frame": (C.c_int, [_VP, P(C.c_double), C.c_uint64]),
+    "vh_sensor_data_get_frame": (C.c_int, [_VP, C.c_uint64, _VP, _VP, P(C.c_float), P(C.c_uint64)]),
+    "vh_sensor_data_reader_create": (C.c_int, [C.c_char_p, P(_VP)]),
+    "vh_sensor_data_reader_destroy": (None, [_VP]),
+    "vh_sensor_data_reader_info": (C.c_int, [_VP, P(T.SensorDataInfo)]),
+    "vh_sensor_data_reader_process_depth": (C.c_int, [_VP, P(C.c_int), P(_VP), P(_VP)]),
+    "vh_sensor_data_reader_get_rigid_transform": (C.c_int, [_VP, C.c_int, P(C.c_float)]),
+    "vh_sensor_data_reader_get_curr_frame": (C.c_int, [_VP, P(C.c_uint32), P(C.c_uint32)]),
     "vh_rgbd_sensor_create": (C.c_int, [P(C.c_uint32), P(C.c_float), _VP, P(_VP)]),
     "vh_rgbd_sensor_destroy": (None, [_VP]),
     "vh_rgbd_sensor_set_filter_depth_values": (C.c_int, [_VP, C.c_int, C.c_float, C.c_float]),

@@ -152,6 +152,17 @@ class AppState(C.Structure):
     ]
 
 
+class SensorDataInfo(C.Structure):
+    """VhSensorDataInfo: the header of a `.sens` sequence"""
+    _fields_ = [
+        ("m_versionNumber", C.c_uint32), ("m_colorCompressionType", C.c_int32), ("m_depthCompressionType", C.c_int32),
+        ("m_colorWidth", C.c_uint32), ("m_colorHeight", C.c_uint32), ("m_depthWidth", C.c_uint32), ("m_depthHeight", C.c_uint32),
+        ("m_depthShift", C.c_float), ("m_numFrames", C.c_uint64), ("m_numIMUFrames", C.c_uint64),
+        ("m_colorIntrinsic", C.c_float * 16), ("m_colorExtrinsic", C.c_float * 16),
+        ("m_depthIntrinsic", C.c_float * 16), ("m_depthExtrinsic", C.c_float * 16), ("m_sensorName", C.c_char * 64),
+    ]
+
+
 class TrackingState(C.Structure):
     _fields_ = [
         ("s_maxLevels", C.c_uint32), ("s_maxOuterIter", C.c_uint32 * 8), ("s_maxInnerIter", C.c_uint32 * 8),
