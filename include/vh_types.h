@@ -240,7 +240,13 @@ typedef struct VhAppState {
     uint32_t s_streamingOutParts;
     uint32_t s_offlineProcessing;
     uint32_t s_sensorIdx;
-    uint32_t numKeysFound; /* how many of the members above the file held */
+    /* recorded sequences: played when s_sensorIdx selects the SensorDataReader (DSC/GlobalAppState.h:51-53,80,95-98) */
+    uint32_t s_binaryDumpSensorUseTrajectory, s_binaryDumpSensorUseTrajectoryOnlyInit;
+    uint32_t s_playData, s_recordData, s_recordCompression, s_reconstructionEnabled;
+    uint32_t s_numBinaryDumpSensorFiles; /* entries s_binaryDumpSensorFile[0..n) the file held, at most 8 kept */
+    char s_binaryDumpSensorFile[8][256];
+    char s_recordDataFile[256];
+    uint32_t numKeysFound; /* how many of the members above the file held (the file list counts once) */
 } VhAppState;
 
 /* GlobalCameraTrackingState (DSC/GlobalCameraTrackingState.h:14-25), per pyramid level; from zParametersTracking*.txt */

@@ -27,7 +27,8 @@ def test_sample_file_and_builders():
     assert list(g.s_streamingVoxelExtents) == [1.0, 1.0, 0.5] and list(g.s_streamingGridDimensions) == [257, 257, 129]
     assert list(g.s_streamingMinGridPos) == [-128, -128, -64]
     assert g.s_trackingEnabled == 0 and g.s_streamingRadius == 0.0                      # absent keys are value-initialised
-    assert g.numKeysFound == 32  # of the members VhAppState has; s_recordDataFile and the two junk lines are not among them
+    assert g.numKeysFound == 33  # of the members VhAppState has; the two junk lines are not among them
+    assert g.s_recordDataFile == b"Dump/test.sens" and g.s_recordData == 0 and g.s_numBinaryDumpSensorFiles == 0
     hp = T.HashParams()
     L.vh_hash_params_from_app_state(C.byref(g), C.byref(hp))
     assert hp.m_hashNumBuckets == 2000000 and hp.m_hashBucketSize == 10 and hp.m_SDFBlockSize == 8 and hp.m_numSDFBlocks == 2097152
@@ -90,3 +91,25 @@ def test_reference_parameter_files(name):
     if name == "zParametersDefault.txt":
         assert (g.s_adapterWidth, g.s_adapterHeight) == (320, 240) and g.s_SDFVoxelSize == f32(0.004) and g.s_hashNumBuckets == 500000
         assert g.s_hashNumSDFBlocks == 1000000 and g.s_depthFilter == 1 and g.s_garbageCollectionEnabled == 0 and g.s_marchingCubesMaxNumTriangles == 2500000
+
+
+def test_recorded_sequence_keys():
+    """the .sens file list is read as mLib reads a std::vector: name[0], name[1], ... until one is missing
+    (parameterFile.h:92-108)"""
+    L = lib.load()
+    g = T.AppState()
+    text = b"""s_sensorIdx = 8;
+s_binaryDumpSensorFile[0] = "./DumpOutput/a_0.sens";
+s_binaryDumpSensorFile[1] = "./DumpOutput/a_1.sens";
+s_binaryDumpSensorFile[3] = "never reached: index 2 is missing";
+s_binaryDumpSensorUseTrajectory = true;
+s_binaryDumpSensorUseTrajectoryOnlyInit = false;	//only valid if prev is true
+s_playData = true;
+s_recordData = false;
+s_reconstructionEnabled = true;
+"""
+    lib.check(L.vh_app_state_parse(text, C.byref(g)), "parse")
+    assert g.s_numBinaryDumpSensorFiles == 2
+    assert bytes(g.s_binaryDumpSensorFile[0].value) == b"./DumpOutput/a_0.sens" and bytes(g.s_binaryDumpSensorFile[1].value) == b"./DumpOutput/a_1.sens"
+    assert (g.s_binaryDumpSensorUseTrajectory, g.s_binaryDumpSensorUseTrajectoryOnlyInit, g.s_playData, g.s_recordData, g.s_reconstructionEnabled) == (1, 0, 1, 0, 1)
+    assert g.numKeysFound == 7  # the list counts once

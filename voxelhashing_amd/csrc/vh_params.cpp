@@ -82,6 +82,14 @@ struct Reader {
         if (!get(name, s)) return;
         out = (s == "false" || s == "False" || s == "0") ? 0u : 1u;
     }
+    void text(const char* name, char* out, size_t cap)
+    {
+        std::string s;
+        out[0] = 0;
+        if (!get(name, s)) return;
+        std::strncpy(out, s.c_str(), cap - 1);
+        out[cap - 1] = 0;
+    }
     template <class T> void vec3(const char* name, T out[3])
     {
         std::string s;
@@ -140,6 +148,23 @@ void fill(const Values& values, VhAppState* out)
     r.vec3("s_streamingPos", out->s_streamingPos);
     r.u32("s_streamingOutParts", out->s_streamingOutParts);
     r.boolean("s_offlineProcessing", out->s_offlineProcessing);
+    r.boolean("s_binaryDumpSensorUseTrajectory", out->s_binaryDumpSensorUseTrajectory);
+    r.boolean("s_binaryDumpSensorUseTrajectoryOnlyInit", out->s_binaryDumpSensorUseTrajectoryOnlyInit);
+    r.boolean("s_playData", out->s_playData);
+    r.boolean("s_recordData", out->s_recordData);
+    r.boolean("s_recordCompression", out->s_recordCompression);
+    r.boolean("s_reconstructionEnabled", out->s_reconstructionEnabled);
+    r.text("s_recordDataFile", out->s_recordDataFile, sizeof(out->s_recordDataFile));
+    // readParameter(name, std::vector<U>&), parameterFile.h:92-108: name[0], name[1], ... until one is missing
+    const uint32_t before = r.found;
+    for (uint32_t i = 0;; i++) {
+        std::string s;
+        if (!r.get(("s_binaryDumpSensorFile[" + std::to_string(i) + "]").c_str(), s)) break;
+        if (i < 8) std::strncpy(out->s_binaryDumpSensorFile[i], s.c_str(), sizeof(out->s_binaryDumpSensorFile[i]) - 1);
+        out->s_numBinaryDumpSensorFiles = i + 1;
+    }
+    if (out->s_numBinaryDumpSensorFiles > 8) out->s_numBinaryDumpSensorFiles = 8;
+    r.found = before + (out->s_numBinaryDumpSensorFiles ? 1u : 0u);
     out->numKeysFound = r.found;
 }
 

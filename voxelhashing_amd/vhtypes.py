@@ -148,6 +148,9 @@ class AppState(C.Structure):
         ("s_streamingVoxelExtents", C.c_float * 3), ("s_streamingGridDimensions", C.c_int32 * 3), ("s_streamingMinGridPos", C.c_int32 * 3),
         ("s_streamingInitialChunkListSize", C.c_uint32), ("s_streamingRadius", C.c_float), ("s_streamingPos", C.c_float * 3),
         ("s_streamingOutParts", C.c_uint32), ("s_offlineProcessing", C.c_uint32), ("s_sensorIdx", C.c_uint32),
+        ("s_binaryDumpSensorUseTrajectory", C.c_uint32), ("s_binaryDumpSensorUseTrajectoryOnlyInit", C.c_uint32),
+        ("s_playData", C.c_uint32), ("s_recordData", C.c_uint32), ("s_recordCompression", C.c_uint32), ("s_reconstructionEnabled", C.c_uint32),
+        ("s_numBinaryDumpSensorFiles", C.c_uint32), ("s_binaryDumpSensorFile", (C.c_char * 256) * 8), ("s_recordDataFile", C.c_char * 256),
         ("numKeysFound", C.c_uint32),
     ]
 
