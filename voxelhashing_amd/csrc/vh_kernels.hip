@@ -830,14 +830,16 @@ VHD bool trilinear(const VhHashData& hd, float vs, LK& lk, int p0in, const Taps&
     const int lx0 = x0 & 7, ly0 = y0 & 7, lz0 = z0 & 7; // = local1(): two's complement & 7 is the non-negative remainder
     const int lx1 = x1 & 7, ly1 = y1 & 7, lz1 = z1 & 7;
     // the eight voxels, in flight together (reference tap order 000,100,010,001,110,011,101,111)
-    const Vox v000 = unpack_vox(load_voxel(hd, p0, lx0, ly0, lz0));
-    const Vox v100 = unpack_vox(load_voxel(hd, p1, lx1, ly0, lz0));
-    const Vox v010 = unpack_vox(load_voxel(hd, p2, lx0, ly1, lz0));
-    const Vox v001 = unpack_vox(load_voxel(hd, p4, lx0, ly0, lz1));
-    const Vox v110 = unpack_vox(load_voxel(hd, p3, lx1, ly1, lz0));
-    const Vox v011 = unpack_vox(load_voxel(hd, p6, lx0, ly1, lz1));
-    const Vox v101 = unpack_vox(load_voxel(hd, p5, lx1, ly0, lz1));
-    const Vox v111 = unpack_vox(load_voxel(hd, p7, lx1, ly1, lz1));
+    uint2 r000 = load_voxel(hd, p0, lx0, ly0, lz0), r100 = load_voxel(hd, p1, lx1, ly0, lz0);
+    uint2 r010 = load_voxel(hd, p2, lx0, ly1, lz0), r001 = load_voxel(hd, p4, lx0, ly0, lz1);
+    uint2 r110 = load_voxel(hd, p3, lx1, ly1, lz0), r011 = load_voxel(hd, p6, lx0, ly1, lz1);
+    uint2 r101 = load_voxel(hd, p5, lx1, ly0, lz1), r111 = load_voxel(hd, p7, lx1, ly1, lz1);
+    // one trip to memory for the eight: left alone the compiler waits for the first pair before it issues the rest
+    // (three trips), and the dearest waves of a frame run at the pace of their own chain of loads
+    asm volatile("" : "+v"(r000.x), "+v"(r000.y), "+v"(r100.x), "+v"(r100.y), "+v"(r010.x), "+v"(r010.y), "+v"(r001.x), "+v"(r001.y),
+                      "+v"(r110.x), "+v"(r110.y), "+v"(r011.x), "+v"(r011.y), "+v"(r101.x), "+v"(r101.y), "+v"(r111.x), "+v"(r111.y));
+    const Vox v000 = unpack_vox(r000), v100 = unpack_vox(r100), v010 = unpack_vox(r010), v001 = unpack_vox(r001);
+    const Vox v110 = unpack_vox(r110), v011 = unpack_vox(r011), v101 = unpack_vox(r101), v111 = unpack_vox(r111);
     // weight byte == 0 for any tap <=> min over the taps of (cw >> 24) == 0
     const uint32_t wmin = min(min(min(v000.cw, v100.cw), min(v010.cw, v001.cw)), min(min(v110.cw, v011.cw), min(v101.cw, v111.cw)));
     if ((wmin >> 24) == 0u) return false;
@@ -1179,6 +1181,14 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
         tile = e.y == phase ? e.x : nTiles; // a slot the dealing left empty (last, partial workgroup)
     }
     if (tile >= nTiles) return;
+    // The launch slots are in order of cost, dearest first.  The dearest waves outlast the others of their SIMD and
+    // then run alone at the pace of their own dependent loads: they are the tail of the kernel.  Issue priority
+    // lets them run at that pace from the start, while the cheap waves fill the gaps.
+    if (sched && sched[0] == phase) {
+        if (waveIdx * 16u < nTiles) __builtin_amdgcn_s_setprio(3);
+        else if (waveIdx * 4u < nTiles) __builtin_amdgcn_s_setprio(2);
+        else if (waveIdx * 2u < nTiles) __builtin_amdgcn_s_setprio(1);
+    }
     int* tab = tileTab[threadIdx.x / kWave];
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
@@ -2419,6 +2429,17 @@ int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData*
     return vh_last_launch_error();
 }
 
+static uint32_t device_num_cus() // of the current device (one device per process: INTEGRATION.md)
+{
+    static int numCUs = 0;
+    if (numCUs == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCUs <= 0)
+            numCUs = 256;
+    }
+    return (uint32_t)numCUs;
+}
+
 size_t vh_render_schedule_bytes(uint32_t width, uint32_t height)
 {
     const size_t tiles = (size_t)cdiv(width, 8) * cdiv(height, 8);
@@ -2464,17 +2485,12 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
 {
     if (!hd || !hp || !cp || !rp || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     if (rp->m_width == 0 || rp->m_height == 0) return VH_OK;
-    static int numCUs = 0; // of the current device (one device per process: INTEGRATION.md)
-    if (d_schedule && numCUs == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCUs <= 0)
-            numCUs = 256;
-    }
+    const uint32_t numCUs = d_schedule ? device_num_cus() : 256u;
     const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
     const uint32_t groups = cdiv(nWords, kSplatWordsPerGroup);
     k_interval_splat<<<groups + (d_schedule ? 1u : 0u), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
                                                                                  reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u,
-                                                                                 d_schedule, phase, (uint32_t)(numCUs > 0 ? numCUs : 256), groups, d_longestList);
+                                                                                 d_schedule, phase, numCUs, groups, d_longestList);
     return vh_last_launch_error();
 }
 
