@@ -76,7 +76,7 @@ VHD bool block_streamed_out(const VhHashParams& hp, I3 blk, const uint32_t* bitM
     return (bitMask[index >> 5] & (1u << (index & 31))) != 0u;
 }
 
-__global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
+__global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
                                                VhDepthCameraParams cp, const uint32_t* bitMask, int32_t lockToken, HashMod hm)
 {
     const uint32_t lane = lane_id();
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void k_alloc(VhHashData hd, VhHashParams hp, V
     const float minDepth = fminf(hp.m_maxIntegrationDistance, d - t);
     const float maxDepth = fminf(hp.m_maxIntegrationDistance, d + t);
     if (minDepth >= maxDepth) active = false;
+    if (!__any(active)) return; // a tile without a measurement
 
     const F3 rayMin = mat_mul_p(hp.m_rigidTransform, depth_to_skeleton(cp, x, y, minDepth));
     const F3 rayMax = mat_mul_p(hp.m_rigidTransform, depth_to_skeleton(cp, x, y, maxDepth));
@@ -2346,7 +2347,7 @@ int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraDa
     const uint32_t tiles = cdiv(cp->m_imageWidth, 8) * cdiv(cp->m_imageHeight, 8);
     if (tiles == 0) return VH_OK;
     if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
-    k_alloc<<<cdiv(tiles, 4), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken, make_hash_mod(hp->m_hashNumBuckets));
+    k_alloc<<<cdiv(tiles, 8), 512, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken, make_hash_mod(hp->m_hashNumBuckets));
     return vh_last_launch_error();
 }
 
