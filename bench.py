@@ -219,7 +219,8 @@ def cpu_baseline(cfg_name, n_frames, args):
 
     dt1, blocks1 = timed(False)
     # a GPU box gives one GPU's share of the host (16 cores): do not let OpenMP start a thread per host core
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0))))))
+    # (set through the library: an OpenMP runtime that numpy or torch already started ignores the environment)
+    O.lib(omp=True).vho_set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     cores = int(O.lib(omp=True).vho_num_threads())
     dtn, blocksn = timed(True)
     if blocks1 != blocksn:

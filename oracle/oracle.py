@@ -29,6 +29,7 @@ def lib(omp=False):
         build()
     L = C.CDLL(path)
     L.vho_num_threads.restype = C.c_int
+    L.vho_set_num_threads.argtypes = [C.c_int]
     P = C.POINTER
     L.vho_hash_data_alloc.argtypes = [P(T.HashData), P(T.HashParams)]
     L.vho_hash_data_alloc.restype = C.c_int

@@ -32,6 +32,16 @@
 #include <omp.h>
 #endif
 
+/* caps the threads of the parallel sections (no-op in the checker's build) */
+void vho_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* threads the parallel sections use: 1 in the checker's build */
 int vho_num_threads(void)
 {

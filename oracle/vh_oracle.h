@@ -31,6 +31,7 @@ int vho_hash_data_alloc(VhHashData* hd, const VhHashParams* hp);
 void vho_hash_data_free(VhHashData* hd);
 
 /* float4x4::getInverse (DSC/cuda_SimpleMatrixUtil.h:944-1069) */
+void vho_set_num_threads(int n);
 int vho_num_threads(void); /* 1 unless built with -fopenmp (libvh_oracle_omp.so, bench baseline only) */
 void vho_mat4_inverse(const float m[16], float out[16]);
 

@@ -602,15 +602,19 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
                     slot[j] = 0xffffffffu;
                     if (i < n) {
                         slot[j] = atomicAdd(&heads[t[j]].z, 1u);
-                        if (cap == 0u) { // intervals only: with lists, k_render derives the interval from the listed blocks
-                            atomicMin(&heads[t[j]].x, lo);
-                            atomicMax(&heads[t[j]].y, hi);
-                        }
                     }
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < kInFlight; j++)
-                    if (slot[j] < cap) lists[(size_t)t[j] * cap + slot[j]] = make_int4(bx, by, bz, ptr);
+                for (uint32_t j = 0; j < kInFlight; j++) {
+                    if (slot[j] < cap) {
+                        lists[(size_t)t[j] * cap + slot[j]] = make_int4(bx, by, bz, ptr);
+                    } else if (slot[j] != 0xffffffffu) {
+                        // the head's depth range covers the blocks that are NOT listed (all of them without lists);
+                        // k_render forms the range of the listed ones itself: two atomics per tile and block less
+                        atomicMin(&heads[t[j]].x, lo);
+                        atomicMax(&heads[t[j]].y, hi);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -736,8 +740,11 @@ struct TileLookup {
     const VhHashParams& hp;
     VHD static uint32_t slot_of(int bx, int by, int bz)
     {
-        // blocks of a tile are neighbours along a beam: a small linear hash spreads them (a 5x5x5 cube maps 1:1)
-        return (uint32_t)(bx + 5 * by + 24 * bz) & (kTileTabSlots - 1u); // shifts and adds only
+        // Multiply-shift hash, three full-rate 24-bit multiplies.  The blocks of a tile are a dense slab along its beam;
+        // a linear form like x + 5y + 24z packs such a slab into ONE contiguous run of slots, and a probe for a block
+        // that is not in the table (every empty-space step of a ray) then walks the whole run: 100 probes instead
+        // of one on the long lists of fine voxels.
+        return ((__umul24((uint32_t)bx, 0x9E3779u) + __umul24((uint32_t)by, 0x7F4A7Du) + __umul24((uint32_t)bz, 0x85EBCBu)) >> 10) & (kTileTabSlots - 1u);
     }
     VHD static int slot_find(const int* tab, int bx, int by, int bz)
     {
@@ -968,7 +975,7 @@ template <bool GRADIENTS, class LK>
 VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
                    uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayHit& out, uint32_t& cost
 #ifdef VH_RENDER_STATS
-                   , float& statTri, float& statIter
+                   , float& statTri, float& statIter, float (&statCyc)[3]
 #endif
 )
 {
@@ -1024,6 +1031,9 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
             Taps tp;
             int p0 = kPtrUnknown;
             int skipped = 0;
+#ifdef VH_RENDER_STATS
+            const long long tA0 = clock64();
+#endif
 #pragma unroll 1
             while (rcur < tStop) {
 #ifdef VH_RENDER_STATS
@@ -1035,6 +1045,10 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
                 skipped = 1;
                 rcur += inc;
             }
+#ifdef VH_RENDER_STATS
+            statCyc[0] += (float)(clock64() - tA0);
+            const long long tB0 = clock64();
+#endif
             if (!(rcur < tStop)) break; // ray left the depth range (or the range in which blocks exist)
             lastValid = skipped ? 0 : lastValid;
 
@@ -1047,6 +1061,9 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
             uint32_t colorUnused = 0u;
             const F3 pos = mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z);
             const bool ok = trilinear<false>(hd, rq.vs, lk, p0, tp, pos, rq.rvs, dist, colorUnused);
+#ifdef VH_RENDER_STATS
+            statCyc[1] += (float)(clock64() - tB0);
+#endif
             if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) { candidate = true; break; }
             lastSdf = ok ? dist : lastSdf;
             lastAlpha = ok ? rcur : lastAlpha;
@@ -1059,6 +1076,9 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
         float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
         uint32_t color2 = 0u;
         bool success = true;
+#ifdef VH_RENDER_STATS
+        const long long tC0 = clock64();
+#endif
 #pragma unroll 1
         for (int i = 0; i < 3; i++) {
 #ifdef VH_RENDER_STATS
@@ -1075,6 +1095,9 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
             if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
             else { b = c; bDist = cDist; }
         }
+#ifdef VH_RENDER_STATS
+        statCyc[2] += (float)(clock64() - tC0);
+#endif
         if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
             out.hit = true;
             out.alpha = c;
@@ -1114,11 +1137,12 @@ VHD void store_ray(const VhRayCastData& rd, const VhDepthCameraParams& cp, size_
 }
 
 #ifdef VH_RENDER_STATS
-#define VH_STAT_DECL const long long statT0 = clock64(); const long long statR0 = wall_clock64(); float statTri = 0.0f, statIter = 0.0f;
-#define VH_STAT_ARGS , statTri, statIter
+#define VH_STAT_DECL const long long statT0 = clock64(); const long long statR0 = wall_clock64(); float statTri = 0.0f, statIter = 0.0f; float statCyc[3] = { 0.0f, 0.0f, 0.0f };
+#define VH_STAT_ARGS , statTri, statIter, statCyc
 #define VH_STAT_STORE                                                                                                                   \
     {                                                                                                                                   \
         const uint32_t hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);              \
+        reinterpret_cast<float4*>(rd.d_depth4)[pix] = make_float4(statCyc[0], statCyc[1], statCyc[2], 0.0f);                             \
         reinterpret_cast<float4*>(rd.d_normals)[pix] = make_float4((float)(clock64() - statT0), statTri, statIter, (float)(wall_clock64() - statR0)); \
         reinterpret_cast<float4*>(rd.d_colors)[pix] = make_float4((float)(uint32_t)(statR0 & 0xffffffll), (float)((hwid >> 8) & 0xfu),  \
             (float)((hwid >> 13) & 0x7u) + 8.0f * (float)((hwid >> 12) & 1u), (float)(xcc & 0xfu) * 4.0f + (float)((hwid >> 4) & 3u));   \
@@ -1238,12 +1262,11 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     __builtin_amdgcn_wave_barrier();
 
     if (cap != 0u) {
-        // With lists the splat keeps no depth range (two atomics per tile and block less): the range of the listed blocks
-        // is formed here.  Camera depth is linear in the world position, so over a (grown) box its extremes are sums of
-        // per-axis extremes; the same margins as k_interval_splat.  An overflowed list knows no range: march it all.
-        tileZmin = 0.0f;
-        tileZmax = pinf();
-        if (complete) {
+        // With lists the splat keeps the depth range of the blocks a full list could not take (head.x, head.y); the
+        // range of the listed blocks is formed here (two atomics per tile and block less).  Camera depth is linear in
+        // the world position, so over a (grown) box its extremes are sums of per-axis extremes; the same margins as
+        // k_interval_splat.
+        {
             const float vs = hp.m_virtualVoxelSize;
             const float growLo = (GRADIENTS ? 1.75f : 1.25f) * vs, growHi = (GRADIENTS ? 0.75f : 0.25f) * vs;
             const float* vm = rp.m_viewMatrix; // camera z of a world point: row 2
@@ -1269,6 +1292,10 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
             for (int off = 32; off > 0; off >>= 1) {
                 zlo = fminf(zlo, __shfl_xor(zlo, off));
                 zhi = fmaxf(zhi, __shfl_xor(zhi, off));
+            }
+            if (!complete) { // {+inf, 0} if nothing overflowed
+                zlo = fminf(zlo, __uint_as_float(head.x));
+                zhi = fmaxf(zhi, __uint_as_float(head.y));
             }
             tileZmin = fmaxf(zlo, 0.0f);  // an empty list leaves {+inf, -inf}: nothing to march
             tileZmax = zhi;
