@@ -1002,7 +1002,12 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
         // Q bounds |pos/voxel| for every sample of this ray (march and bisection parameters are <= rayEnd)
         const float Q = 1.0f + (fabsf(rq.camq.x) + fabsf(rq.camq.y) + fabsf(rq.camq.z)) +
                         fabsf(rayEnd) * (fabsf(rq.dirq.x) + fabsf(rq.dirq.y) + fabsf(rq.dirq.z));
-        const float margin = Q * (32.0f / 16777216.0f);
+        // Margin: 16 u Q with u = 2^-24.  Per axis, with S = (|cam| + t |dir|) / voxel <= Q - 1: the fused route
+        // q = fma(t, dir * r, cam * r), r = fl(1 / voxel), is within 3 u S of the real (cam + t dir) / voxel (r, the
+        // two scaled operands, the fma); the reference's route -- fl(t dir), + cam, - half, / voxel, +- 0.5, and for
+        // the upper tap + voxel before the division -- within u (6 S + 5.5) of the same number.  Both take the floor:
+        // they agree when q is further than u (9 S + 5.5) < 16 u Q from an integer.
+        const float margin = Q * (16.0f / 16777216.0f);
         rq.certLim = (Q < 65536.0f) ? 0.5f - margin : -1.0f; // NaN/inf Q compare false: exact path
     }
 
