@@ -1255,11 +1255,15 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
 #pragma unroll
         for (uint32_t k = 0; k < kPerLane; k++) {
             if (lane + k * kWave < listed) {
-#pragma unroll 1
+                // the seven first probes in flight together (the slots are scattered: one probe nearly always settles it)
+                int nb[8];
+#pragma unroll
                 for (uint32_t j = 1; j < 8u; j++) {
                     const int sl = Lookup::slot_find(tab, mine[k].x + (int)(j & 1u), mine[k].y + (int)((j >> 1) & 1u), mine[k].z + (int)((j >> 2) & 1u));
-                    tab[slot[k] * kTileSlotWords + 3u + j] = sl >= 0 ? tab[(uint32_t)sl * kTileSlotWords + 3u] : VH_FREE_ENTRY;
+                    nb[j] = sl >= 0 ? tab[(uint32_t)sl * kTileSlotWords + 3u] : VH_FREE_ENTRY;
                 }
+#pragma unroll
+                for (uint32_t j = 1; j < 8u; j++) tab[slot[k] * kTileSlotWords + 3u + j] = nb[j];
             }
         }
     }
