@@ -189,3 +189,52 @@ def test_errors(tmp_path):
         sd.frame(0)
     with pytest.raises(VhError, match="raw"):
         sd.addFrame(recs[0][1], recs[0][0])  # no JPEG encoder: raw pixels cannot go into a JPEG sequence
+
+
+def test_damaged_colour_and_depth_streams_are_refused_not_crashed(tmp_path):
+    """random damage to JPEG / PNG / zlib frames: every outcome is a decoded image or a VhError"""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    y, x = np.mgrid[0:CH, 0:CW]
+    img = np.stack([(5 * x) % 256, (9 * y) % 256, (3 * x + 4 * y) % 256], axis=-1).astype(np.uint8)
+    streams = {}
+    for name, kw in (("JPEG", dict(quality=90, subsampling=2)), ("PNG", {})):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format=name, **kw)
+        streams[name] = buf.getvalue()
+    depth = np.arange(DW * DH, dtype=np.uint16).reshape(DH, DW)
+    outcomes = {"ok": 0, "refused": 0}
+    for name, ctype in (("JPEG", SD.TYPE_JPEG), ("PNG", SD.TYPE_PNG)):
+        good = bytearray(streams[name])
+        for trial in range(150):
+            b = bytearray(good)
+            kind = trial % 3
+            if kind == 0:    # flip a few bytes
+                for _ in range(1 + trial % 5):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 1:  # truncate
+                b = b[:int(rng.integers(1, len(b)))]
+            else:            # splice garbage in
+                at = int(rng.integers(0, len(b)))
+                b[at:at] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+            sd = SD.SensorData.create((DW, DH), (CW, CH), np.eye(4), color_type=ctype, depth_type=SD.TYPE_RAW_USHORT)
+            sd.addFrame(bytes(b), depth)
+            try:
+                out = sd.frame(0)["color"]
+                assert out.shape == (CH, CW, 3)
+                outcomes["ok"] += 1
+            except VhError:
+                outcomes["refused"] += 1
+    assert outcomes["refused"] > 50 and outcomes["ok"] + outcomes["refused"] == 300
+    # a damaged zlib depth frame in a file
+    recs = frames(1)
+    z = bytearray(zlib.compress(recs[0][0].tobytes()))
+    for trial in range(40):
+        b = bytearray(z)
+        b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        path = tmp_path / "d.sens"
+        path.write_bytes(pack_file(b"x", 0, 1, 1000.0, recs, 0, [], [recs[0][1].tobytes()], [bytes(b)]))
+        try:
+            SD.SensorData.loadFromFile(path).frame(0)
+        except VhError:
+            pass

@@ -38,10 +38,17 @@ namespace {
 struct FileReader {
     std::FILE* f;
     std::string name;
+    uint64_t size = 0;
     explicit FileReader(const std::string& path) : f(std::fopen(path.c_str(), "rb")), name(path)
     {
         if (!f) fail(VH_ERR_IO, "could not open file " + path); // sensorData.h:792-794
+        if (std::fseek(f, 0, SEEK_END) == 0) {
+            const long n = std::ftell(f);
+            size = n > 0 ? (uint64_t)n : 0;
+        }
+        std::rewind(f);
     }
+    uint64_t remaining() const { const long at = std::ftell(f); return at >= 0 && (uint64_t)at <= size ? size - (uint64_t)at : 0; }
     ~FileReader() { if (f) std::fclose(f); }
     bool tryRead(void* dst, size_t n) { return n == 0 || std::fread(dst, 1, n, f) == n; }
     void read(void* dst, size_t n, const char* what)
@@ -431,14 +438,17 @@ struct JpegDecoder {
             const size_t next = pos + (size_t)len;
             if (m == 0xDB) readDqt(len);
             else if (m == 0xC4) readDht(len);
-            else if (m == 0xC0 || m == 0xC1) readSof(len);
+            else if (m == 0xC0 || m == 0xC1) {
+                readSof(len);
+                // before anything is allocated for it
+                if ((uint32_t)width != wantW || (uint32_t)height != wantH) bad("frame has a different size than the file header says");
+            }
             else if (m == 0xC2) bad("progressive JPEG is not supported");
             else if (m >= 0xC3 && m <= 0xCF && m != 0xC8 && m != 0xCC) bad("lossless / arithmetic JPEG is not supported");
             else if (m == 0xDD) restartInterval = word();
             pos = next;
         }
         if (!scanned) bad("no image data");
-        if ((uint32_t)width != wantW || (uint32_t)height != wantH) bad("frame has a different size than the file header says");
         if (nComp == 1) {
             for (int y = 0; y < height; y++)
                 for (int x = 0; x < width; x++) {
@@ -492,7 +502,7 @@ void SensorData::loadFromFile(const std::string& filename) // :789-830
     if (m_versionNumber != kVersion) // assertVersionNumber :647-650
         fail(VH_ERR_VERSION_MISMATCH, "Invalid file version -- found " + std::to_string(m_versionNumber) + " but expected " + std::to_string(kVersion));
     const uint64_t strLen = in.get<uint64_t>("the header");
-    if (strLen > (1u << 20)) fail(VH_ERR_IO, filename + ": sensor name length is implausible");
+    if (strLen > in.remaining()) fail(VH_ERR_IO, filename + ": file ends inside the sensor name");
     m_sensorName.assign((size_t)strLen, '\0');
     in.read(&m_sensorName[0], (size_t)strLen, "the sensor name");
     in.read(m_colorIntrinsic.m, 64, "the calibration"); in.read(m_colorExtrinsic.m, 64, "the calibration");
@@ -507,13 +517,14 @@ void SensorData::loadFromFile(const std::string& filename) // :789-830
     if ((uint64_t)m_depthWidth * m_depthHeight > (1ull << 28) || (uint64_t)m_colorWidth * m_colorHeight > (1ull << 28))
         fail(VH_ERR_IO, filename + ": image size is implausible");
     const uint64_t numFrames = in.get<uint64_t>("the header");
-    m_frames.reserve((size_t)std::min<uint64_t>(numFrames, 1u << 20));
+    m_frames.reserve((size_t)std::min<uint64_t>(numFrames, in.remaining() / 96)); // a frame is at least 96 bytes
     for (uint64_t i = 0; i < numFrames; i++) { // RGBDFrame::loadFromFile :512-523
         RGBDFrame f;
         in.read(f.m_cameraToWorld.m, 64, "a frame");
         f.m_timeStampColor = in.get<uint64_t>("a frame"); f.m_timeStampDepth = in.get<uint64_t>("a frame");
         const uint64_t colorBytes = in.get<uint64_t>("a frame"), depthBytes = in.get<uint64_t>("a frame");
-        if (colorBytes > (1ull << 31) || depthBytes > (1ull << 31)) fail(VH_ERR_IO, filename + ": frame " + std::to_string(i) + " has an implausible size");
+        // a damaged size field must not turn into a giant allocation: the data has to be in the file
+        if (colorBytes > in.remaining() || depthBytes > in.remaining() - colorBytes) fail(VH_ERR_IO, filename + ": file ends inside a frame's data");
         f.m_colorCompressed.resize((size_t)colorBytes); f.m_depthCompressed.resize((size_t)depthBytes);
         in.read(f.m_colorCompressed.data(), (size_t)colorBytes, "a frame's colour data");
         in.read(f.m_depthCompressed.data(), (size_t)depthBytes, "a frame's depth data");
