@@ -99,6 +99,8 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
 /* ---- ray-cast launchers: DSC/CUDARayCastSDF.cpp:10-21 ----------------------- */
 /* renderCS(const HashData&, const RayCastData&, const DepthCameraData&, const RayCastParams&)
  *                                                               DSC/CUDARayCastSDF.cu:59 */
+/* d_normals of the VhRayCastData may be NULL for vh_render / vh_render_intervals: the map is then not written (the
+ * host class does so when vh_compute_normals overwrites it right after). */
 int vh_render(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd,
               const VhDepthCameraParams* cp, const VhRayCastParams* rp, vhStream_t stream);
 /* Ray-interval splatting as a compute pass: resetRayIntervalSplatCUDA / rayIntervalSplatCUDA

@@ -628,10 +628,14 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
         if (timedAll) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
     }
     if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
+    // Without gradients computeNormals rewrites every pixel of the normal map right after (MINF or a normal,
+    // DSC/CameraUtil.cu:669-697), so the march does not write its MINF there first: a null map is skipped.
+    RayCastData out = m_data;
+    if (!m_params.m_useGradients) out.d_normals = nullptr;
     if (m_useIntervals) {
-        check(vh_render_intervals(&hashData, &hashParams, &m_data, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, m_stream), "renderCS");
+        check(vh_render_intervals(&hashData, &hashParams, &out, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, m_stream), "renderCS");
     } else {
-        check(vh_render(&hashData, &hashParams, &m_data, &cp, &m_params, m_stream), "renderCS");
+        check(vh_render(&hashData, &hashParams, &out, &cp, &m_params, m_stream), "renderCS");
     }
     if (timed) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {

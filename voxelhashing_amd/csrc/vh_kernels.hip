@@ -1137,7 +1137,7 @@ VHD void store_ray(const VhRayCastData& rd, const VhDepthCameraParams& cp, size_
     }
     rd.d_depth[pix] = depth;
     reinterpret_cast<float4*>(rd.d_depth4)[pix] = depth4;
-    reinterpret_cast<float4*>(rd.d_normals)[pix] = normal;
+    if (rd.d_normals) reinterpret_cast<float4*>(rd.d_normals)[pix] = normal; // a null map is not written (vh_api.h)
     reinterpret_cast<float4*>(rd.d_colors)[pix] = color;
 }
 
