@@ -1211,14 +1211,6 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
         tile = e.y == phase ? e.x : nTiles; // a slot the dealing left empty (last, partial workgroup)
     }
     if (tile >= nTiles) return;
-    // The launch slots are in order of cost, dearest first.  The dearest waves outlast the others of their SIMD and
-    // then run alone at the pace of their own dependent loads: they are the tail of the kernel.  Issue priority
-    // lets them run at that pace from the start, while the cheap waves fill the gaps.
-    if (sched && sched[0] == phase) {
-        if (waveIdx * 16u < nTiles) __builtin_amdgcn_s_setprio(3);
-        else if (waveIdx * 4u < nTiles) __builtin_amdgcn_s_setprio(2);
-        else if (waveIdx * 2u < nTiles) __builtin_amdgcn_s_setprio(1);
-    }
     int* tab = tileTab[threadIdx.x / kWave];
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
