@@ -163,3 +163,38 @@ def test_exact_shortcuts(vh, voxel, buckets):
     mism = buf.download(np.uint32)
     assert mism[0] == 0, f"div_exact differs from IEEE division on {mism[0]} operands"
     assert mism[1] == 0, f"umod_fast differs from % on {mism[1]} operands"
+
+
+def general_poses(n, seed):
+    """camera-to-world matrices with every rotation axis in play: the orbit pose, then roll / pitch / yaw of up to 25
+    degrees about the camera's own axes and a shift of up to 20 cm (the orbit alone only ever turns about y)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        base = np.asarray(synth.orbit_pose(int(rng.integers(0, 200)), 200), np.float64).reshape(4, 4)
+        a, b, c = np.radians(rng.uniform(-25, 25, size=3))
+        rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+        local = np.eye(4)
+        local[:3, :3] = rz @ ry @ rx
+        local[:3, 3] = rng.uniform(-0.2, 0.2, size=3)
+        out.append((base @ local).astype(np.float32).reshape(16))
+    return out
+
+
+@pytest.mark.parametrize("params,gradients,seed", [("P4", False, 1), ("P2", False, 2), ("P2", True, 3), ("P1", False, 4)])
+def test_general_camera_orientations(E, oracle_lib, params, gradients, seed):
+    """rays and frusta with all three direction components of either sign, non-axis-aligned image planes: alloc's
+    DDA, the frustum tests, the fused / exact voxel-index routes of the ray caster and the splat's projections all
+    against the oracle, bit for bit, on the four-sphere scene"""
+    O = oracle_lib
+    hp, cp, rp = small_config(112, 80, params, 1 << 14, 1 << 14)
+    rp = T.make_raycast_params(hp, cp, use_gradients=gradients)
+    poses = general_poses(5, seed)
+    g_scene, g_ray, o_scene = run_pair(E, O, hp, cp, rp, T.make_scene_options(offline=True, gc=True, starve=3), poses, synth.S3_SPHERES)
+    assert g_scene.getNumOccupiedBlocks() > 40
+    # and from a viewpoint nothing was integrated from
+    view = general_poses(1, seed + 100)[0]
+    g_ray.render(g_scene.getHashData(), g_scene.getHashParams(), cp, view)
+    assert_maps_equal(g_ray.download(), o_scene.render(view), "novel view")
