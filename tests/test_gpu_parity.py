@@ -198,3 +198,38 @@ def test_general_camera_orientations(E, oracle_lib, params, gradients, seed):
     view = general_poses(1, seed + 100)[0]
     g_ray.render(g_scene.getHashData(), g_scene.getHashParams(), cp, view)
     assert_maps_equal(g_ray.download(), o_scene.render(view), "novel view")
+
+
+@pytest.mark.parametrize("params,seed", [("P4", 11), ("P2", 12)])
+def test_noisy_depth_with_holes(E, oracle_lib, params, seed):
+    """what a sensor delivers rather than an analytic surface: centimetre noise, pixels without a measurement (MINF and
+    0), readings beyond the integration distance, colour missing where depth is present and the other way round"""
+    O = oracle_lib
+    hp, cp, rp = small_config(128, 96, params, 1 << 14, 1 << 14)
+    opt = T.make_scene_options(offline=True, gc=True, starve=2)
+    rng = np.random.default_rng(seed)
+    g_scene, g_ray, o_scene = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp), O.OracleScene(hp, cp, rp, opt)
+    last = None
+    minf = np.float32(-np.inf)
+    for k in range(5):
+        pose = synth.orbit_pose(3 * k, 120)
+        depth, color = O.synth_frame(synth.S3_SPHERES, 0, pose, cp)
+        valid = np.isfinite(depth)
+        depth = np.where(valid, depth + rng.normal(0.0, 0.01, depth.shape).astype(np.float32), depth).astype(np.float32)
+        u = rng.random(depth.shape)
+        depth[u < 0.06] = minf
+        depth[(u >= 0.06) & (u < 0.09)] = 0.0
+        depth[(u >= 0.09) & (u < 0.11)] = 4.5            # beyond m_maxIntegrationDistance
+        depth[(u >= 0.11) & (u < 0.12)] = 3.9999         # just inside it
+        color = color.copy()
+        color[(u >= 0.5) & (u < 0.55)] = minf            # no colour here: such pixels are not integrated
+        color[..., :3] = np.where(np.isfinite(color[..., :3]), rng.random(color[..., :3].shape).astype(np.float32), color[..., :3])
+        frame = E.DepthFrame(cp, depth=depth, color=color)
+        if last is not None:
+            g_ray.render(g_scene.getHashData(), g_scene.getHashParams(), cp, last)
+            assert_maps_equal(g_ray.download(), o_scene.render(last), f"frame {k} raycast")
+        g_scene.integrate(pose, frame, cp, None)
+        o_scene.integrate(pose, depth, color)
+        canonical.assert_same_scene(g_scene.state(), o_scene.state(), f"frame {k}")
+        last = pose
+    assert g_scene.getNumOccupiedBlocks() > 60
