@@ -99,3 +99,24 @@ def test_product_package_never_touches_the_oracle():
                 if re.search(r"(from|import)\s+oracle|libvh_oracle|vh_oracle\.h|vho_", txt):
                     bad.append(f)
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_every_entry_point_refuses_null_arguments():
+    """all pointers NULL, all numbers 0: an error code, never a crash and never a launch (the arguments are checked
+    before anything touches the device).  vh_bind_input_depth_color_textures is the reference's texture binding: a
+    documented no-op."""
+    import ctypes as C
+    from voxelhashing_amd import lib
+    L = lib.load()
+    checked = 0
+    for name, (res, args) in lib.PROTOTYPES.items():
+        if res is not C.c_int:
+            continue
+        vals = [0 if a in (C.c_int, C.c_uint32, C.c_uint64, C.c_int32, C.c_size_t) else 0.0 if a in (C.c_float, C.c_double) else None for a in args]
+        rc = getattr(L, name)(*vals)
+        if name == "vh_bind_input_depth_color_textures":
+            assert rc == 0
+        else:
+            assert rc != 0, name
+        checked += 1
+    assert checked > 120
