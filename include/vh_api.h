@@ -45,6 +45,8 @@ int vh_free(void* devPtr);
 int vh_memcpy_h2d(void* dst, const void* src, size_t bytes, vhStream_t stream);
 int vh_memcpy_d2h(void* dst, const void* src, size_t bytes, vhStream_t stream); /* synchronises the stream */
 int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream);
+int vh_stream_create(vhStream_t* out);   /* a non-blocking HIP stream, for FFI users without a HIP binding */
+int vh_stream_destroy(vhStream_t stream);
 int vh_stream_synchronize(vhStream_t stream);
 int vh_device_synchronize(void);
 

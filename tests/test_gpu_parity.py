@@ -233,3 +233,38 @@ def test_noisy_depth_with_holes(E, oracle_lib, params, seed):
         canonical.assert_same_scene(g_scene.state(), o_scene.state(), f"frame {k}")
         last = pose
     assert g_scene.getNumOccupiedBlocks() > 60
+
+
+def test_explicit_stream_gives_the_same_scene(E, oracle_lib):
+    """every launch and copy of the classes goes to the stream they were given: a scene, ray caster, chunk grid, sensor
+    and tracker built on a private non-blocking stream (nothing else synchronises it with the null stream) produce the
+    oracle's results like the default-stream ones"""
+    import ctypes as C
+    from voxelhashing_amd import lib
+    O = oracle_lib
+    L = lib.load()
+    st = C.c_void_p()
+    lib.check(L.vh_stream_create(C.byref(st)), "vh_stream_create")
+    try:
+        hp, cp, rp = small_config(96, 72, "P2", 1 << 13, 1 << 13)
+        opt = T.make_scene_options(offline=True, gc=True, starve=2)
+        g_scene, g_ray = E.CUDASceneRepHashSDF(hp, opt, stream=st), E.CUDARayCastSDF(rp, stream=st)
+        o_scene = O.OracleScene(hp, cp, rp, opt)
+        frame = E.DepthFrame(cp, stream=st)
+        last = None
+        for k in range(6):
+            pose = synth.orbit_pose(k, 60)
+            E.synth_frame(synth.S3_SPHERES, 0, pose, cp, out=frame, stream=st)
+            depth, color = O.synth_frame(synth.S3_SPHERES, 0, pose, cp)
+            if last is not None:
+                g_ray.render(g_scene.getHashData(), g_scene.getHashParams(), cp, last)
+                assert_maps_equal(g_ray.download(), o_scene.render(last), f"frame {k} raycast")
+            g_scene.integrate(pose, frame, cp, None)
+            o_scene.integrate(pose, depth, color)
+            last = pose
+        canonical.assert_same_scene(g_scene.state(), o_scene.state(), "explicit stream")
+    finally:
+        for obj in ("g_scene", "g_ray"):
+            if obj in locals():
+                locals()[obj].close()
+        lib.check(L.vh_stream_destroy(st), "vh_stream_destroy")

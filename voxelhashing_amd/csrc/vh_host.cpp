@@ -85,6 +85,20 @@ int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream)
     VH_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
     return VH_OK;
 }
+int vh_stream_create(vhStream_t* out)
+{
+    if (!out) return VH_ERR_BAD_ARGUMENT;
+    hipStream_t s = nullptr;
+    VH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (vhStream_t)s;
+    return VH_OK;
+}
+int vh_stream_destroy(vhStream_t stream)
+{
+    if (!stream) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipStreamDestroy((hipStream_t)stream));
+    return VH_OK;
+}
 int vh_stream_synchronize(vhStream_t stream)
 {
     VH_HIP(hipStreamSynchronize((hipStream_t)stream));

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "vh_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "vh_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "vh_memset": (C.c_int, [_VP, C.c_int, C.c_size_t, _VP]),
+    "vh_stream_create": (C.c_int, [P(_VP)]),
+    "vh_stream_destroy": (C.c_int, [_VP]),
     "vh_stream_synchronize": (C.c_int, [_VP]),
     "vh_device_synchronize": (C.c_int, []),
     "vh_hash_data_alloc": (C.c_int, [P(T.HashData), P(T.HashParams)]),
