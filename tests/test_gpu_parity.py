@@ -268,3 +268,43 @@ def test_explicit_stream_gives_the_same_scene(E, oracle_lib):
             if obj in locals():
                 locals()[obj].close()
         lib.check(L.vh_stream_destroy(st), "vh_stream_destroy")
+
+
+def test_two_scenes_on_two_streams_interleaved(E, oracle_lib):
+    """one instance = one scene: two scenes with different parameters, each on its own stream, advanced in turns
+    without any synchronisation between them, each equal to its own oracle (no state is shared between instances)"""
+    import ctypes as C
+    from voxelhashing_amd import lib
+    O = oracle_lib
+    L = lib.load()
+    streams, rigs = [], []
+    try:
+        for params, spheres, size in (("P4", synth.S1_SPHERES, (96, 72)), ("P2", synth.S3_SPHERES, (80, 64))):
+            st = C.c_void_p()
+            lib.check(L.vh_stream_create(C.byref(st)), "vh_stream_create")
+            streams.append(st)
+            hp, cp, rp = small_config(size[0], size[1], params, 1 << 13, 1 << 13)
+            opt = T.make_scene_options(offline=True, gc=True, starve=2)
+            rigs.append(dict(cp=cp, spheres=spheres, st=st, scene=E.CUDASceneRepHashSDF(hp, opt, stream=st), ray=E.CUDARayCastSDF(rp, stream=st),
+                             oracle=O.OracleScene(hp, cp, rp, opt), frame=E.DepthFrame(cp, stream=st), last=None))
+        for k in range(5):
+            for r in rigs:  # enqueue both before looking at either
+                pose = synth.orbit_pose(2 * k, 60)
+                E.synth_frame(r["spheres"], 0, pose, r["cp"], out=r["frame"], stream=r["st"])
+                if r["last"] is not None:
+                    r["ray"].render(r["scene"].getHashData(), r["scene"].getHashParams(), r["cp"], r["last"])
+                r["scene"].integrate(pose, r["frame"], r["cp"], None)
+            for r in rigs:
+                pose = synth.orbit_pose(2 * k, 60)
+                depth, color = O.synth_frame(r["spheres"], 0, pose, r["cp"])
+                if r["last"] is not None:
+                    assert_maps_equal(r["ray"].download(), r["oracle"].render(r["last"]), f"frame {k} raycast")
+                r["oracle"].integrate(pose, depth, color)
+                canonical.assert_same_scene(r["scene"].state(), r["oracle"].state(), f"frame {k}")
+                r["last"] = pose
+    finally:
+        for r in rigs:
+            r["scene"].close()
+            r["ray"].close()
+        for st in streams:
+            lib.check(L.vh_stream_destroy(st), "vh_stream_destroy")
