@@ -432,6 +432,14 @@ VHD void divmod_small(uint32_t i, uint32_t nx, float rnx, uint32_t& q, uint32_t&
 constexpr uint32_t kCostSample = 6;
 constexpr uint32_t kCostClasses = 32;
 constexpr uint32_t kCostClassWidth = 8;
+// The dearest tiles of a frame are marched by TWO waves of one workgroup, each one half of the tile's depth interval:
+// a wave alone on its SIMD runs at the pace of its own chain of dependent loads, and the few tiles with the longest
+// rays (a silhouette grazing the truncation band) are the tail of the kernel.  A sample's state is the previous
+// sample's alone, so the far half starts at the last sample before the middle with nothing remembered and arrives at
+// the middle in the state the whole march would have; the near half's hit, if any, is the first along the ray.
+constexpr uint32_t kSplitTiles = 64;      // even: two split tiles fill a workgroup
+constexpr uint32_t kSplitMinTiles = 1024; // smaller images are not split
+__host__ __device__ inline uint32_t split_tiles(uint32_t nTiles) { return nTiles >= kSplitMinTiles ? kSplitTiles : 0u; }
 
 // Launch order of the next k_render (one workgroup of k_interval_splat, beside the others): tiles sorted by the cost
 // class the previous k_render stored, dearest first, dealt to the workgroups (4 tiles each) in rows of numCUs that
@@ -442,6 +450,7 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
     // layout: {phase the slots were made for, -, -, -}, cost class per tile, {tile, phase} per launch slot
     const uint32_t* cls = sched + 4;
     uint2* slots = reinterpret_cast<uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u));
+    const uint32_t nSplit = split_tiles(nTiles);
     if (threadIdx.x == 0) {
         sched[0] = phase;
         if (feedback) *feedback = sched[1]; // longest tile list the previous k_render met (0: none near the small capacity)
@@ -490,7 +499,8 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
         for (uint32_t j = 0; j < 4u; j++) { sCount[kBins + kBins - 1u - (lane * 4u + j)] = start; start += n[j]; }
     }
     __syncthreads();
-    const uint32_t nGroups = (nTiles + 3u) / 4u, fullRows = nGroups / numCUs;
+    // launch slots: the nSplit dearest tiles take two each (near half, far half; two tiles to a workgroup), the others one
+    const uint32_t nGroups = (nTiles + nSplit + 3u) / 4u, fullRows = nGroups / numCUs;
     for (uint32_t q0 = threadIdx.x; q0 < nQuads; q0 += blockDim.x * kBatch) {
         uint4 c[kBatch];
 #pragma unroll
@@ -506,10 +516,17 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
                 const uint32_t t = (q0 + j * blockDim.x) * 4u + k;
                 if (t < nTiles) {
                     const uint32_t i = atomicAdd(&sCount[kBins + min(cc[k], kCostClasses - 1u) * kSub + sub], 1u); // rank of tile t
-                    uint32_t g = i / 4u;
-                    const uint32_t row = g / numCUs, col = g % numCUs;
-                    if ((row & 1u) && row < fullRows) g = row * numCUs + (numCUs - 1u - col);
-                    slots[g * 4u + (i & 3u)] = make_uint2(t, phase);
+                    if (i < nSplit) {
+                        const uint32_t at = (i / 2u) * 4u + (i & 1u) * 2u;
+                        slots[at] = make_uint2(t | (1u << 24), phase);
+                        slots[at + 1u] = make_uint2(t | (2u << 24), phase);
+                    } else {
+                        const uint32_t j = i + nSplit;
+                        uint32_t g = j / 4u;
+                        const uint32_t row = g / numCUs, col = g % numCUs;
+                        if ((row & 1u) && row < fullRows) g = row * numCUs + (numCUs - 1u - col);
+                        slots[g * 4u + (j & 3u)] = make_uint2(t, phase);
+                    }
                 }
             }
         }
@@ -973,7 +990,7 @@ struct RayHit {
 // each ray's own sequence of samples is the reference's.
 template <bool GRADIENTS, class LK>
 VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
-                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, RayHit& out, uint32_t& cost
+                   uint32_t x, uint32_t y, float tileZmin, float tileZmax, uint32_t half, float zMid, RayHit& out, uint32_t& cost
 #ifdef VH_RENDER_STATS
                    , float& statTri, float& statIter, float (&statCyc)[3]
 #endif
@@ -1019,9 +1036,22 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
     // (they are invalid: lastValid = 0), samples after it likewise, so nothing can be hit there.  rcur still
     // advances by the same sequence of additions, one VALU op per skipped sample.
     const float tSkip = depthToRayLength * tileZmin;
-    const float tStop = fminf(rayEnd, depthToRayLength * tileZmax);
+    float tStop = fminf(rayEnd, depthToRayLength * tileZmax);
 #pragma unroll 1
     while (rcur < tSkip && rcur < rayEnd) rcur += inc;
+    if (half != 0u) { // half of a split tile (wave-uniform): the near one samples before tMid, the far one from the last sample before it
+        const float tMid = depthToRayLength * zMid;
+        if (half == 1u) {
+            tStop = fminf(tStop, tMid);
+        } else {
+#pragma unroll 1
+            for (;;) {
+                const float nxt = rcur + inc; // the same additions the march makes
+                if (!(nxt < tMid) || !(nxt < rayEnd)) break;
+                rcur = nxt;
+            }
+        }
+    }
 
 #pragma unroll 1
     for (;;) {
@@ -1177,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_render_hash(VhHashData hd, VhHashParams
     HashLookup lk{ hd, hp, hm, {} };
     cache_init(lk.bc);
     uint32_t cost = 0u;
-    march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, 0.0f, pinf(), out, cost VH_STAT_ARGS);
+    march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, 0.0f, pinf(), 0u, 0.0f, out, cost VH_STAT_ARGS);
     store_ray(rd, cp, pix, x, y, out, GRADIENTS);
     VH_STAT_STORE
 }
@@ -1205,17 +1235,18 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     // i+2 numCUs, ... in launch order.  k_interval_splat sorts the tiles by the cost the previous frame measured
     // (it differs little) and deals them to the workgroups so that the sums come out even.  The schedule carries the
     // phase it was made for: one that was not refreshed for this call is ignored (raster order).
-    uint32_t tile = waveIdx;
+    uint32_t tile = waveIdx, half = 0u; // half: 0 whole tile, 1 / 2 near / far half of a split tile (all four waves of a workgroup or none)
     if (sched && sched[0] == phase) {
         const uint2 e = reinterpret_cast<const uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u))[waveIdx];
-        tile = e.y == phase ? e.x : nTiles; // a slot the dealing left empty (last, partial workgroup)
+        tile = e.y == phase ? (e.x & 0xffffffu) : nTiles; // a slot the dealing left empty (last, partial workgroup)
+        half = e.y == phase ? (e.x >> 24) : 0u;
     }
     if (tile >= nTiles) return;
     int* tab = tileTab[threadIdx.x / kWave];
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
     float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y); // as splatted (lists == nullptr)
-    if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
+    if (lane == 0 && half == 0u) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u); // (a split tile: once both halves have read it)
     const uint32_t listed = min(head.z, min(cap, CAP));
     const bool complete = listed == head.z;
     // feedback for the host's choice of CAP: the longest list of the frame (only lists near the small capacity report)
@@ -1311,17 +1342,37 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     uint32_t cost = 0u;
     if (inImage && tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
         Lookup lk{ tab, complete, hd, hp };
-        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, out, cost VH_STAT_ARGS);
+        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, half, 0.5f * (tileZmin + tileZmax), out, cost VH_STAT_ARGS);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cost = max(cost, (uint32_t)__shfl_xor((int)cost, off));
+    if (half != 0u) {
+        // the far half leaves its result in its (spent) table, the near half takes it where it found nothing itself
+        int* mine = tab;
+        int* other = tileTab[(threadIdx.x / kWave) ^ 1u];
+        if (half == 2u) {
+            mine[lane * 8u + 0u] = out.hit ? 1 : 0;
+            mine[lane * 8u + 1u] = __float_as_int(out.alpha);
+            mine[lane * 8u + 2u] = (int)out.color;
+            if (GRADIENTS) { mine[lane * 8u + 3u] = __float_as_int(out.normal.x); mine[lane * 8u + 4u] = __float_as_int(out.normal.y); mine[lane * 8u + 5u] = __float_as_int(out.normal.z); }
+            if (lane == 0) mine[64u * 8u] = (int)cost;
+        }
+        __syncthreads(); // all four waves of this workgroup are halves of split tiles (schedule_tiles)
+        if (half == 2u) return;
+        if (!out.hit && other[lane * 8u + 0u] != 0) {
+            out.hit = true;
+            out.alpha = __int_as_float(other[lane * 8u + 1u]);
+            out.color = (uint32_t)other[lane * 8u + 2u];
+            if (GRADIENTS) out.normal = mk3(__int_as_float(other[lane * 8u + 3u]), __int_as_float(other[lane * 8u + 4u]), __int_as_float(other[lane * 8u + 5u]));
+        }
+        cost += (uint32_t)other[64u * 8u];
+        if (lane == 0) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u);
     }
     if (inImage) {
         store_ray(rd, cp, pix, x, y, out, GRADIENTS);
         VH_STAT_STORE
     }
-    if (sched) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cost = max(cost, (uint32_t)__shfl_xor((int)cost, off));
-        if (lane == 0) sched[4 + tile] = min(cost / kCostClassWidth, kCostClasses - 1u); // plain store: nobody waits for it
-    }
+    if (sched && lane == 0) sched[4 + tile] = min(cost / kCostClassWidth, kCostClasses - 1u); // plain store: nobody waits for it
 }
 #undef VH_STAT_DECL
 #undef VH_STAT_ARGS
@@ -2472,7 +2523,8 @@ static uint32_t device_num_cus() // of the current device (one device per proces
 size_t vh_render_schedule_bytes(uint32_t width, uint32_t height)
 {
     const size_t tiles = (size_t)cdiv(width, 8) * cdiv(height, 8);
-    return (4u + 4u * ((tiles + 3u) / 4u) + 2u * 4u * ((tiles + 3u) / 4u)) * sizeof(uint32_t); // header, cost classes, launch slots
+    // header, cost classes, launch slots (one per wave: the tiles, and a second one for each split tile)
+    return (4u + 4u * ((tiles + 3u) / 4u) + 2u * 4u * ((tiles + kSplitTiles + 3u) / 4u)) * sizeof(uint32_t);
 }
 
 int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
@@ -2487,7 +2539,7 @@ int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRa
     const uint32_t cap = d_tileBlocks ? tileCapacity : 0u;
     // the capacity of the lists picks the table size: up to VH_TILE_LIST_CAPACITY the small tables, beyond it the large ones
     const bool large = cap > (uint32_t)VH_TILE_LIST_CAPACITY;
-    const dim3 grid(cdiv(tiles, 4));
+    const dim3 grid(cdiv(tiles + (d_schedule ? split_tiles(tiles) : 0u), 4));
     hipStream_t st = (hipStream_t)stream;
     if (rp->m_useGradients) {
         if (large) k_render_large<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
