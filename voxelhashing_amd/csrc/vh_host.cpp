@@ -645,7 +645,9 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     // Without gradients computeNormals rewrites every pixel of the normal map right after (MINF or a normal,
     // DSC/CameraUtil.cu:669-697), so the march does not write its MINF there first: a null map is skipped.
     RayCastData out = m_data;
+#ifndef VH_RENDER_STATS // (the instrumented build of scratch/ writes its counters into the maps)
     if (!m_params.m_useGradients) out.d_normals = nullptr;
+#endif
     if (m_useIntervals) {
         check(vh_render_intervals(&hashData, &hashParams, &out, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, m_stream), "renderCS");
     } else {
