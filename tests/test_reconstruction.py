@@ -159,3 +159,22 @@ s_binaryDumpSensorUseTrajectory = true;
     assert 0.8 * total < on_gpu + on_host <= total, (on_gpu, on_host, total)
     mesh = rec.extractIsoSurface()
     assert len(mesh["faces"]) > 8000
+
+
+def test_recorded_trajectory_as_initial_guess(vh, oracle_lib, tmp_path):
+    """s_binaryDumpSensorUseTrajectoryOnlyInit: the recorded motion between two frames moves the model view before ICP
+    runs (DepthSensing.cpp:757-765); the tracked poses stay on the recorded trajectory (here the true one, so the
+    initial guess is already the answer and ICP must not walk away from it)"""
+    from voxelhashing_amd import reconstruction as R
+    O = oracle_lib
+    path = str(tmp_path / "s3.sens")
+    poses, _ = make_sequence(path, O)
+    g = app_state("s_binaryDumpSensorUseTrajectory = true;\ns_binaryDumpSensorUseTrajectoryOnlyInit = true;\n")
+    rec = R.Reconstruction(g, sens_files=[path])
+    assert rec.run() == N and rec.lost_frames == 0
+    assert np.array_equal(rec.trajectory[0], np.asarray(poses[0]).reshape(4, 4))  # the first frame has nothing to track against
+    for k in range(1, N):
+        rel = np.linalg.inv(rec.trajectory[k].astype(np.float64)) @ np.asarray(poses[k], np.float64).reshape(4, 4)
+        ang = np.degrees(np.arccos(np.clip(0.5 * (np.trace(rel[:3, :3]) - 1.0), -1, 1)))
+        assert np.linalg.norm(rel[:3, 3]) < 0.004 and ang < 0.1, (k, np.linalg.norm(rel[:3, 3]), ang)
+        assert not np.array_equal(rec.trajectory[k], np.asarray(poses[k]).reshape(4, 4))  # it is ICP's pose, not the file's
