@@ -1,6 +1,7 @@
 """Oracle twin of the camera tracking: CUDACameraTrackingMultiRes::applyCT
 (DSC/CUDACameraTrackingMultiRes.cpp:241-321) in numpy -- per-pixel arithmetic in float32 as the kernels do it, the
-sums of the linear system in float64, the 6x6 solve by numpy's SVD.  TEST INFRASTRUCTURE ONLY (see oracle/vh_oracle.h).
+sums of the linear system in float64, the 6x6 solve by numpy's SVD.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (the
+reference ships no fixtures for this path and cannot be built here: see oracle/vh_oracle.h).
 """
 import numpy as np
 
