@@ -137,8 +137,11 @@ __global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, V
             want = !quad_matches(q0, id);
         }
         if (want) want = block_in_frustum(hp, cp, id) && !block_streamed_out(hp, id, bitMask);
-        // wave-level de-duplication of the requested block ids
+        // wave-level de-duplication of the requested block ids: one lane per distinct id, and those lanes allocate
+        // side by side -- the chain lock -> heap counter -> heap slot -> entry is four trips to memory, walked once
+        // for all the new blocks of this step instead of once per block
         uint64_t pending = __ballot(want);
+        bool leads = false;
         while (pending) {
             const int leader = __ffsll((unsigned long long)pending) - 1;
             const int bx = __builtin_amdgcn_readlane(id.x, leader);
@@ -146,8 +149,9 @@ __global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, V
             const int bz = __builtin_amdgcn_readlane(id.z, leader);
             const bool same = want && id.x == bx && id.y == by && id.z == bz;
             pending &= ~__ballot(same);
-            if ((int)lane == leader) alloc_block(hd, hp, mki3(bx, by, bz), lockToken);
+            leads = leads || (int)lane == leader;
         }
+        if (leads) alloc_block(hd, hp, id, lockToken);
         if (active) {
             if (tMax.x < tMax.y && tMax.x < tMax.z) {
                 id.x = f2i((float)id.x + step.x);
