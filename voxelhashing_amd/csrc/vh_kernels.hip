@@ -532,7 +532,8 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
                         const uint32_t j = i + nSplit;
                         uint32_t g = j / 4u;
                         const uint32_t row = g / numCUs, col = g % numCUs;
-                        if ((row & 1u) && row < fullRows) g = row * numCUs + (numCUs - 1u - col);
+                        // (a row that also holds split tiles keeps its order: their slots are fixed)
+                        if ((row & 1u) && row < fullRows && row * numCUs >= nSplit / 2u) g = row * numCUs + (numCUs - 1u - col);
                         slots[g * 4u + (j & 3u)] = make_uint2(t, phase);
                     }
                 }
