@@ -151,6 +151,7 @@ public:
     // marchOnly: events around the march kernel only; stride n: only every n-th render() is timed
     void setTiming(bool on, bool marchOnly = false, unsigned int stride = 1);
     void getTimings(double out[4]); // ms: raycast (the march kernel), normals, frames, interval splat
+    double getEventPairOverheadMs(); // average reading of an empty HIP event pair (taken while every stage is timed)
     // ray-interval splatting (DSC/CUDARayCastSDF.cpp:84-100, disabled in the reference fork): on by default here,
     // as a conservative compute pass that leaves every output bit unchanged
     void setIntervalSplatting(bool on) { m_useIntervals = on; }

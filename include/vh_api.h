@@ -215,6 +215,9 @@ int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out);
 /* device time in ms of render() accumulated while timing is enabled: {raycast (march kernel), normals, count,
  * interval splat} */
 int vh_raycast_get_timings(VhRayCast* r, double out[4]);
+/* ms an event pair reads with nothing between its two records (sampled while every stage is timed): what a bracketed
+ * launch's reading holds beside the kernel */
+int vh_raycast_get_event_pair_overhead(VhRayCast* r, double* ms);
 int vh_raycast_set_timing(VhRayCast* r, int enabled); /* 0 off, 1 every stage, 2 the march kernel only */
 /* same, timing only every stride-th render() (an event record idles the queue for a few microseconds) */
 int vh_raycast_set_timing_stride(VhRayCast* r, int enabled, uint32_t stride);

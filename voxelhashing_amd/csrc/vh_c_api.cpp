@@ -160,6 +160,11 @@ int vh_raycast_get_timings(VhRayCast* r, double out[4])
     if (!r || !out) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { r->impl.getTimings(out); });
 }
+int vh_raycast_get_event_pair_overhead(VhRayCast* r, double* ms)
+{
+    if (!r || !ms) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { *ms = r->impl.getEventPairOverheadMs(); });
+}
 int vh_raycast_set_interval_splatting(VhRayCast* r, int enabled)
 {
     if (!r) return VH_ERR_BAD_ARGUMENT;

@@ -240,7 +240,7 @@ vec3f mat4f::transformPoint(const vec3f& v) const
 // CUDASceneRepHashSDF
 // ---------------------------------------------------------------------------
 
-enum { ST_ALLOC = 0, ST_COMPACTIFY = 1, ST_INTEGRATE = 2, ST_RAYCAST = 0, ST_NORMALS = 1, ST_SPLAT = 2 };
+enum { ST_ALLOC = 0, ST_COMPACTIFY = 1, ST_INTEGRATE = 2, ST_RAYCAST = 0, ST_NORMALS = 1, ST_SPLAT = 2, ST_EMPTY = 3 };
 
 VhSceneOptions CUDASceneRepHashSDF::defaultOptions()
 {
@@ -602,8 +602,15 @@ void CUDARayCastSDF::setTiming(bool on, bool marchOnly, unsigned int stride)
 {
     m_timeMarchOnly = marchOnly;
     m_timeStride = stride ? stride : 1u;
-    if (on && !m_timer) m_timer = new VhStageTimer(3);
+    if (on && !m_timer) m_timer = new VhStageTimer(4);
     if (!on && m_timer) { delete m_timer; m_timer = nullptr; }
+}
+
+double CUDARayCastSDF::getEventPairOverheadMs()
+{
+    if (!m_timer) return 0.0;
+    m_timer->resolve((hipStream_t)m_stream);
+    return m_timer->count[ST_EMPTY] ? m_timer->totalMs[ST_EMPTY] / (double)m_timer->count[ST_EMPTY] : 0.0;
 }
 
 void CUDARayCastSDF::getTimings(double out[4])
@@ -640,6 +647,10 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
         m_tileCapacity = m_largeTables ? VH_TILE_LIST_CAPACITY_LARGE : VH_TILE_LIST_CAPACITY;
         check(vh_ray_interval_splat(&hashData, &hashParams, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, d_longestList, m_stream), "rayIntervalSplatCUDA");
         if (timedAll) m_timer->stop(ST_SPLAT, (hipStream_t)m_stream);
+    }
+    if (timedAll) { // what an event pair reads with nothing between its two records: the share of a bracketed launch that is not the kernel
+        m_timer->start(ST_EMPTY, (hipStream_t)m_stream);
+        m_timer->stop(ST_EMPTY, (hipStream_t)m_stream);
     }
     if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
     // Without gradients computeNormals rewrites every pixel of the normal map right after (MINF or a normal,

@@ -223,6 +223,11 @@ class CUDARayCastSDF:
         check(self.L.vh_raycast_get_timings(self.handle, out), "getTimings")
         return dict(raycast_ms=out[0], normals_ms=out[1], frames=int(out[2]), splat_ms=out[3])
 
+    def getEventPairOverheadMs(self):
+        out = C.c_double(0.0)
+        check(self.L.vh_raycast_get_event_pair_overhead(self.handle, C.byref(out)), "getEventPairOverhead")
+        return out.value
+
     def download(self):
         rd = self.getRayCastData()
         W, H = self._params.m_width, self._params.m_height

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "vh_raycast_get_data": (C.c_int, [_VP, P(T.RayCastData)]),
     "vh_raycast_get_params": (C.c_int, [_VP, P(T.RayCastParams)]),
     "vh_raycast_get_timings": (C.c_int, [_VP, P(C.c_double)]),
+    "vh_raycast_get_event_pair_overhead": (C.c_int, [_VP, P(C.c_double)]),
     "vh_raycast_set_timing": (C.c_int, [_VP, C.c_int]),
     "vh_raycast_set_timing_stride": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "vh_raycast_set_interval_splatting": (C.c_int, [_VP, C.c_int]),
