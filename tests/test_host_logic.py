@@ -94,3 +94,28 @@ def test_canonical_snapshot_is_order_independent(oracle_lib):
     c = canonical.snapshot(table, newvox.reshape(-1), heap, hc, sc.hp)
     with pytest.raises(AssertionError):
         canonical.assert_same_scene(a, c, "changed")
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """the last bench line kept under profiles/ (written by bench.py on the GPU box) carries every field the driver's
+    contract names, with the types and relations it states"""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_g_bench_line.json")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-3  # one frame per step, one GPU
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.5
+    assert abs(r["avg_launch_us"] - (r["event_pair_us"] - r["event_pair_overhead_us"])) < 1e-2
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "frames/s" and c["value"] > c["single_thread"] > 0
