@@ -8,23 +8,27 @@ alloc + compactify + integrate + garbage-collect + raycast + normals per frame,
 in the reference's order (render with the previous pose, then integrate;
 DepthSensingCUDA/Source/DepthSensing.cpp:763,903).  A "step" is one frame.
 Inputs (depth + colour of every frame) are generated on the device before the
-timed region and stay resident in HBM.
+timed region and stay resident in HBM.  The frame loop is native
+(vh_reconstruction_run, include/vh_api.h): one host call enqueues all frames.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one process per GPU, one independent
-scene per GPU (orbit phase-shifted by 2*pi*rank/8); weak scaling; RCCL is used
-only for the start/stop barriers and a MAX-reduce of the elapsed time.
+N > 1: one process per GPU (started by torch.distributed.run, or by this script
+itself when WORLD_SIZE is not set), one independent scene per GPU (orbit
+phase-shifted by 2*pi*rank/8); weak scaling; RCCL is used only for the
+start/stop barriers and a MAX / SUM reduce of two scalars.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed
-inside the timed region) and `cpu_baseline` (the CPU oracle timed on a bounded
-sample of the same workload, rank 0 at N=1).
+inside the timed region, plus entries for the integrate kernel) and
+`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload,
+rank 0 at N=1).
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -32,12 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+METRIC = "depth frames/sec integrate+raycast @640x480, 4 cm voxel; HBM GB/s vs peak"
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=900)
@@ -49,11 +52,46 @@ def parse_args():
     p.add_argument("--cpu-frames", type=int, default=40, help="frames of the workload timed on the CPU oracle")
     p.add_argument("--stages", action="store_true", help="also print per-stage device times to stderr")
     p.add_argument("--scene", default=None, help="override the scene (S1, S2)")
-    p.add_argument("--event-stride", type=int, default=8, help="HIP events around k_render on every n-th timed frame")
-    return p.parse_args()
+    p.add_argument("--event-stride", type=int, default=0, help="HIP events around k_render on every n-th timed frame (0: 1 below 64 steps, else 8)")
+    p.add_argument("--no-alloc-ahead", action="store_true", help="alloc + compactify on the main stream, behind the ray cast")
+    p.add_argument("--no-streaming", action="store_true", help="cfg3 without its per-frame stream out / stream in")
+    p.add_argument("--frames-in-flight", type=int, default=16, help="frames the host may run ahead of the device (0: no bound)")
+    p.add_argument("--preroll-seconds", type=float, default=0.3, help="untimed device pre-roll before the warm-up (clocks, code objects)")
+    p.add_argument("--no-extra-legs", action="store_true", help="skip the dense-scene integrate leg, the host-fed leg and cfg1")
+    p.add_argument("--python-loop", action="store_true", help="drive the frames from Python (two ctypes calls per frame) instead of the native loop")
+    p.add_argument("--standin", action="store_true", help="TEST ONLY: a CPU stand-in workload (no GPU, no engine) to exercise the multi-rank harness")
+    return p.parse_args(argv)
 
 
-def dist_setup(n_gpus):
+# ---------------------------------------------------------------------------------------------------------------
+# ranks
+# ---------------------------------------------------------------------------------------------------------------
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks of this script (fresh processes, before anything here touches the
+    GPU), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: ranks exited with {codes}")
+    return 0
+
+
+def dist_setup(n_gpus, force_cpu=False):
     """-> (rank, world, local_rank, dist or None)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if n_gpus <= 1 and world <= 1:
@@ -64,7 +102,7 @@ def dist_setup(n_gpus):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    backend = "nccl" if (torch.cuda.is_available() and not force_cpu) else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -96,64 +134,6 @@ def sum_over_ranks(dist_mod, value, device):
     return float(t.item())
 
 
-class GpuWorkload:
-    """one scene on one GPU: pre-generated frames + the reference frame loop"""
-
-    def __init__(self, cfg_name, n_frames, rank, args):
-        import torch
-        from voxelhashing_amd import engine as E, synth, vhtypes as T
-        self.torch, self.E, self.T, self.synth = torch, E, T, synth
-        cfg = dict(synth.CONFIGS[cfg_name])
-        if args.scene:
-            cfg["scene"] = args.scene
-        self.cfg = cfg
-        self.hp, self.cp, self.rp = synth.config_params(cfg)
-        # stage timers (HIP events around every stage) are switched on for a slice of the warm-up only;
-        # the timed region records events around the dominant kernel (raycast) alone
-        self.opt = T.make_scene_options(offline=args.offline, gc=not args.no_gc, starve=15, timings=False)
-        spheres, inside, radius = synth.scene(cfg["scene"])
-        self.n_frames = n_frames
-        phase = 2.0 * math.pi * rank / 8.0
-        self.poses = [synth.orbit_pose(k, 1000, radius, phase) for k in range(n_frames)]
-        self.dev = torch.device("cuda", torch.cuda.current_device())
-        H, W = self.cp.m_imageHeight, self.cp.m_imageWidth
-        # inputs resident in HBM: torch owns the frame store, the engine reads raw pointers
-        self.depth = torch.empty((n_frames, H, W), dtype=torch.float32, device=self.dev)
-        self.color = torch.empty((n_frames, H, W, 4), dtype=torch.float32, device=self.dev)
-        self.frames = []
-        for k in range(n_frames):
-            fr = E.DepthFrame(self.cp, depth_ptr=self.depth[k].data_ptr(), color_ptr=self.color[k].data_ptr())
-            E.synth_frame(spheres, inside, self.poses[k], self.cp, out=fr)
-            self.frames.append(fr)
-        self.scene = E.CUDASceneRepHashSDF(self.hp, self.opt)
-        self.ray = E.CUDARayCastSDF(self.rp)
-        self.event_stride = max(int(getattr(args, 'event_stride', 8)), 1)
-        # live HIP events around k_render in the timed region, on every event_stride-th frame (an event record idles
-        # the queue for ~5 us, so bracketing every launch would cost ~10 % of the frame rate being measured)
-        self.ray.setTiming(True, march_only=True, stride=self.event_stride)
-        self.hd = self.scene.getHashData()
-        torch.cuda.synchronize()
-
-    def run(self, k0, k1):
-        """frames k0..k1-1 of the sequence in the reference's order"""
-        scene, ray, cp, hd = self.scene, self.ray, self.cp, self.hd
-        for k in range(k0, k1):
-            if k > 0:
-                ray.render(hd, scene.getHashParams(), cp, self.poses[k - 1])
-            scene.integrate(self.poses[k], self.frames[k], cp, None)
-
-    def stage_timers(self, on):
-        self.opt.s_timingsDetailledEnabled = 1 if on else 0
-        self.scene.setOptions(self.opt)
-        self.ray.setTiming(True, march_only=not on, stride=1 if on else self.event_stride)
-
-    def timings(self):
-        s = self.scene.getTimings()
-        r = self.ray.getTimings()
-        s.update(r)
-        return s
-
-
 def run_timed(workload, warmup, steps, dist_mod, device, sync=lambda: None, after_warmup=lambda: None, skip_warmup=False):
     """the measurement contract: `warmup` untimed frames, then exactly `steps` frames bracketed by a barrier
     and a device synchronisation on both sides; the elapsed time is the MAX over ranks and the unit count the
@@ -174,6 +154,169 @@ def run_timed(workload, warmup, steps, dist_mod, device, sync=lambda: None, afte
     return elapsed, total
 
 
+class StandinWorkload:
+    """TEST ONLY (--standin): a fixed CPU delay per frame, so that the rank launch, the barriers and the reductions of
+    this script can be exercised on a machine without a GPU.  Nothing of the engine (or of the oracle) runs."""
+
+    def __init__(self, rank):
+        self.frames_done = 0
+        self.rank = rank
+
+    def run(self, k0, k1):
+        for _ in range(k0, k1):
+            time.sleep(0.002)
+            self.frames_done += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the GPU workload
+# ---------------------------------------------------------------------------------------------------------------
+
+class GpuWorkload:
+    """one scene on one GPU: pre-generated frames + the reference frame loop (native: Reconstruction)"""
+
+    def __init__(self, cfg_name, n_frames, rank, args, scene=None, frames_on_host=False, streaming=None):
+        import numpy as np
+        import torch
+        from voxelhashing_amd import engine as E, synth, vhtypes as T
+        self.torch, self.E, self.T, self.synth, self.np = torch, E, T, synth, np
+        cfg = dict(synth.CONFIGS[cfg_name])
+        if scene or args.scene:
+            cfg["scene"] = scene or args.scene
+        self.cfg = cfg
+        self.cfg_name = cfg_name
+        self.hp, self.cp, self.rp = synth.config_params(cfg)
+        self.streaming = bool(cfg.get("streaming")) and not args.no_streaming if streaming is None else streaming
+        # stage timers (HIP events around every stage) are switched on for a slice of the warm-up only;
+        # the timed region records events around the dominant kernel (raycast) alone
+        self.opt = T.make_scene_options(offline=args.offline, gc=not args.no_gc, starve=15, timings=False)
+        spheres, inside, radius = synth.scene(cfg["scene"])
+        self.n_frames = n_frames
+        phase = 2.0 * math.pi * rank / 8.0
+        self.poses = [synth.orbit_pose(k, 1000, radius, phase) for k in range(n_frames)]
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        H, W = self.cp.m_imageHeight, self.cp.m_imageWidth
+        # inputs resident in HBM: torch owns the frame store, the engine reads raw pointers
+        self.depth = torch.empty((n_frames, H, W), dtype=torch.float32, device=self.dev)
+        self.color = torch.empty((n_frames, H, W, 4), dtype=torch.float32, device=self.dev)
+        self.frames = []
+        for k in range(n_frames):
+            fr = E.DepthFrame(self.cp, depth_ptr=self.depth[k].data_ptr(), color_ptr=self.color[k].data_ptr())
+            E.synth_frame(spheres, inside, self.poses[k], self.cp, out=fr)
+            self.frames.append(fr)
+        torch.cuda.synchronize()
+        self.frames_on_host = frames_on_host
+        if frames_on_host:
+            # what a sensor delivers (RGBDSensor::getDepthFloat / getColorRGBX): float depth + RGBX bytes, pinned
+            self.h_depth = torch.empty((n_frames, H, W), dtype=torch.float32).pin_memory()
+            self.h_color = torch.empty((n_frames, H, W, 4), dtype=torch.uint8).pin_memory()
+            self.h_depth.copy_(self.depth)
+            self.h_color.copy_((self.color.clamp(0.0, 1.0) * 255.0).to(torch.uint8))
+            torch.cuda.synchronize()
+            del self.depth, self.color
+            depth_ptrs = [self.h_depth[k].data_ptr() for k in range(n_frames)]
+            color_ptrs = [self.h_color[k].data_ptr() for k in range(n_frames)]
+        else:
+            depth_ptrs = [f.depth_ptr for f in self.frames]
+            color_ptrs = [f.color_ptr for f in self.frames]
+        self.seq = E.Reconstruction.makeFrames(self.poses, depth_ptrs, color_ptrs)
+        self.scene = E.CUDASceneRepHashSDF(self.hp, self.opt)
+        self.ray = E.CUDARayCastSDF(self.rp)
+        self.grid = None
+        ropt = dict(s_allocAhead=0 if args.no_alloc_ahead else 1, s_framesOnHost=1 if frames_on_host else 0,
+                    s_maxFramesInFlight=max(int(args.frames_in_flight), 0))
+        if self.streaming:
+            # DSC/DepthSensing.cpp:610-618 + :1340-1355: 1 m chunks, 257^3, the reference's 80 parts, worker thread on
+            ext = [self.hp.m_streamingVoxelExtents[i] for i in range(3)]
+            dims = [self.hp.m_streamingGridDimensions[i] for i in range(3)]
+            mn = [self.hp.m_streamingMinGridPos[i] for i in range(3)]
+            self.grid = E.CUDASceneRepChunkGrid(self.scene, ext, dims, mn, self.hp.m_streamingInitialChunkListSize, True, self.opt.s_streamingOutParts)
+            pos, rad = synth.streaming_sphere(self.hp, self.cp)
+            ropt.update(s_streamingEnabled=1, s_streamingPos=pos, s_streamingRadius=rad)
+        self.recon = E.Reconstruction(self.scene, self.ray, self.grid, self.cp, E.Reconstruction.defaultOptions(**ropt))
+        self.python_loop = bool(args.python_loop)
+        self.event_stride = 1
+        self.hd = self.scene.getHashData()
+        torch.cuda.synchronize()
+
+    def set_event_stride(self, stride):
+        # live HIP events around k_render in the timed region, on every stride-th frame (an event record idles the
+        # queue for ~5 us: bracketing every launch of a long run would cost ~10 % of the frame rate being measured)
+        self.event_stride = max(int(stride), 1)
+        self.ray.setTiming(True, march_only=True, stride=self.event_stride)
+
+    def run(self, k0, k1):
+        """frames k0..k1-1 of the sequence in the reference's order"""
+        if not self.python_loop:
+            self.recon.run(self.seq, k0, k1 - k0)
+            return
+        scene, ray, cp, hd = self.scene, self.ray, self.cp, self.hd
+        for k in range(k0, k1):
+            if k > 0:
+                ray.render(hd, scene.getHashParams(), cp, self.poses[k - 1])
+            scene.integrate(self.poses[k], self.frames[k], cp, None)
+
+    def restart(self):
+        """back to an empty scene and frame 0 (after the pre-roll)"""
+        self.recon.synchronize()
+        if self.grid is not None:
+            self.grid.reset()
+        self.scene.reset()
+        self.recon.reset()
+        self.hd = self.scene.getHashData()
+
+    def stage_timers(self, on):
+        self.opt.s_timingsDetailledEnabled = 1 if on else 0
+        self.scene.setOptions(self.opt)
+        self.ray.setTiming(True, march_only=not on, stride=1 if on else self.event_stride)
+
+    def timings(self):
+        s = self.scene.getTimings()
+        r = self.ray.getTimings()
+        s.update(r)
+        return s
+
+    def stage_sample(self, k0, k1):
+        """frames k0..k1-1 with every stage bracketed by HIP events -> per-stage device time in us per frame"""
+        torch = self.torch
+        self.recon.synchronize()
+        s0 = self.timings()
+        self.stage_timers(True)
+        self.run(k0, k1)
+        self.recon.synchronize()
+        torch.cuda.synchronize()
+        s1 = self.timings()
+        self.stage_timers(False)
+        n = max(k1 - k0, 1)
+        return {k[:-3]: 1e3 * (s1[k] - s0[k]) / n for k in ("alloc_ms", "compactify_ms", "integrate_ms", "splat_ms", "raycast_ms", "normals_ms")}
+
+    def close(self):
+        self.recon.synchronize()
+        self.recon.close()
+        if self.grid is not None:
+            self.grid.close()
+        self.ray.close()
+        self.scene.close()
+
+
+def preroll(wl, seconds):
+    """untimed: the sequence's first frames over and over until the device has been busy for `seconds` (clocks up, code
+    objects loaded, first-touch of every buffer done); the scene is emptied again afterwards"""
+    if seconds <= 0:
+        return 0
+    t0 = time.perf_counter()
+    n = min(wl.n_frames, 64)
+    done = 0
+    while time.perf_counter() - t0 < seconds:
+        wl.run(0, n)
+        wl.recon.synchronize()
+        done += n
+        if wl.streaming:  # frame 0 again on a scene whose far side has been streamed out would only churn the host grid
+            wl.restart()
+    wl.restart()
+    return done
+
+
 def stage_bytes(cfg_hp, cp, n_occ, stage):
     """ALGORITHMIC bytes per launch (E = 20 B entry payload, V = 8 B voxel)"""
     W, H = cp.m_imageWidth, cp.m_imageHeight
@@ -189,6 +332,14 @@ def stage_bytes(cfg_hp, cp, n_occ, stage):
     if stage == "normals":
         return (16.0 * 5 + 16.0) * W * H
     raise KeyError(stage)
+
+
+def integrate_roofline(kernel_us, n_occ, hp, cp, what):
+    b = stage_bytes(hp, cp, n_occ, "integrate")
+    gbs = b / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
+    return dict(bound="hbm", kernel="k_integrate<fused> (integrate + starve + GC)", workload=what, achieved=round(gbs, 3), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes=b, avg_launch_us=round(kernel_us, 3),
+                blocks_in_frustum=n_occ)
 
 
 def cpu_baseline(cfg_name, n_frames, args):
@@ -230,10 +381,72 @@ def cpu_baseline(cfg_name, n_frames, args):
                        f"{dtn:.1f} s; oracle/libvh_oracle.so on 1 thread {dt1:.1f} s")
 
 
-def main():
-    args = parse_args()
-    rank, world, local_rank, dist_mod = dist_setup(args.gpus)
+def cfg1_leg(args):
+    """BASELINE.json configs[0]: ONE 640x480 frame, 4 cm voxels, 2^18 buckets, alloc until fixed point + compactify +
+    integrate + GC, then the ray cast from the same pose: the HIP path and the CPU oracle (1 thread, all cores) side by side"""
     import torch
+    from oracle import oracle as O
+    from voxelhashing_amd import engine as E, synth, vhtypes as T
+    hp, cp, rp = synth.config_params("cfg1")
+    opt = T.make_scene_options(offline=True, gc=True, starve=15)
+    spheres, inside, radius = synth.scene("S1")
+    pose = synth.orbit_pose(0, 1000, radius, 0.0)
+    scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+    fr = E.synth_frame(spheres, inside, pose, cp)
+    gpu = []
+    for _ in range(3):  # the first pass loads code objects
+        scene.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scene.integrate(pose, fr, cp, None)
+        ray.render(scene.getHashData(), scene.getHashParams(), cp, pose)
+        torch.cuda.synchronize()
+        gpu.append(time.perf_counter() - t0)
+    blocks = scene.getNumOccupiedBlocks()
+    ray.close()
+    scene.close()
+    depth, color = O.synth_frame(spheres, inside, pose, cp)
+    out = dict(workload="cfg1: one S1 frame, 640x480, P4, 2^18 buckets, offline alloc + compactify + integrate + gc + raycast",
+               gpu_ms=round(1e3 * min(gpu), 3), blocks_in_frustum=int(blocks))
+    for omp in (False, True):
+        if omp:
+            O.lib(omp=True).vho_set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        sc = O.OracleScene(hp, cp, rp, opt, omp=omp)
+        t0 = time.perf_counter()
+        sc.integrate(pose, depth, color)
+        sc.render(pose)
+        dt = time.perf_counter() - t0
+        if int(sc.hp.m_numOccupiedBlocks) != int(blocks):
+            raise RuntimeError(f"cfg1: oracle {sc.hp.m_numOccupiedBlocks} blocks, HIP path {blocks}")
+        sc.close()
+        out["cpu_all_cores_ms" if omp else "cpu_1_thread_ms"] = round(1e3 * dt, 1)
+    out["cpu_cores"] = int(O.lib(omp=True).vho_num_threads())
+    return out
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    rank, world, local_rank, dist_mod = dist_setup(args.gpus, force_cpu=args.standin)
+    import torch
+
+    if args.standin:
+        dev = torch.device("cpu")
+        wl = StandinWorkload(rank)
+        elapsed, total_frames = run_timed(wl, args.warmup, args.steps, dist_mod, dev)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 6),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                              "data": "STANDIN: no GPU work, harness test only", "config": {"workload": "stand-in (sleep)"},
+                              "roofline": None, "cpu_baseline": None}), flush=True)
+        if dist_mod is not None:
+            dist_mod.barrier()
+            dist_mod.destroy_process_group()
+        return 0
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -241,65 +454,70 @@ def main():
 
     n_frames = args.warmup + args.steps
     wl = GpuWorkload(args.config, n_frames, rank, args)
+    stride = args.event_stride if args.event_stride > 0 else (1 if args.steps < 64 else 8)
+    wl.set_event_stride(stride)
 
-    # warm-up, untimed.  Its last frames run with every stage timer on: per-stage device times of the steady state.
-    n_stage = min(64, args.warmup)
+    # untimed pre-roll (set-up): the device is busy with this workload's own kernels before anything is measured
+    preroll_frames = preroll(wl, args.preroll_seconds)
+
+    # warm-up, untimed.  Its last frames (never frame 0: the empty table) run with every stage timer on: per-stage
+    # device times of the steady state.
+    n_stage = min(64, max(args.warmup - 1, 0))
     wl.run(0, args.warmup - n_stage)
-    torch.cuda.synchronize()
-    s0 = wl.timings()
-    wl.stage_timers(True)
-    wl.run(args.warmup - n_stage, args.warmup)
-    torch.cuda.synchronize()
-    s1 = wl.timings()
-    wl.stage_timers(False)
-    stage_us = {k[:-3]: 1e3 * (s1[k] - s0[k]) / max(n_stage, 1) for k in ("alloc_ms", "compactify_ms", "integrate_ms", "splat_ms", "raycast_ms", "normals_ms")}
+    stage_us = wl.stage_sample(args.warmup - n_stage, args.warmup) if n_stage else {}
 
     pre = {}
+    st0 = {}
 
     def after_warmup():
         torch.cuda.synchronize()
         pre.update(wl.timings())  # the timed region starts from here
+        st0.update(wl.recon.getStats())
 
     elapsed, total_frames = run_timed(wl, args.warmup, args.steps, dist_mod, dev, sync=torch.cuda.synchronize,
                                       after_warmup=after_warmup, skip_warmup=True)
     value = total_frames / elapsed
     post = wl.timings()
+    st1 = wl.recon.getStats()
     n_occ = wl.scene.getNumOccupiedBlocks()
+    host_enqueue_us = 1e6 * (st1["hostEnqueueSeconds"] - st0["hostEnqueueSeconds"]) / max(args.steps, 1)
+    host_wait_us = 1e6 * (st1["hostWaitSeconds"] - st0["hostWaitSeconds"]) / max(args.steps, 1)
 
-    # dominant kernel: HIP events on the launch stream around k_render, every frame of the timed region
+    # dominant kernel: HIP events on the launch stream around k_render, inside the timed region
     launches = max(int(post["frames"] - pre["frames"]), 1)
-    dominant = max(stage_us, key=stage_us.get) if n_stage else "raycast"
-    if dominant != "raycast":
-        print(f"note: dominant stage is {dominant}; live events cover raycast only", file=sys.stderr)
-        dominant = "raycast"
+    dominant = max(stage_us, key=stage_us.get) if stage_us else "raycast"
     pair_us = 1e3 * (post["raycast_ms"] - pre["raycast_ms"]) / launches
     # An event pair reads a few microseconds with nothing between its two records (the records themselves): that
     # share, sampled with empty pairs while the warm-up timed every stage, is not the kernel's.
     overhead_us = 1e3 * wl.ray.getEventPairOverheadMs()
     dom_us = pair_us - overhead_us if 0.0 < overhead_us < 0.5 * pair_us else pair_us
-    alg_bytes = stage_bytes(wl.hp, wl.cp, n_occ, dominant)
+    W, H = wl.cp.m_imageWidth, wl.cp.m_imageHeight
+    alg_bytes = stage_bytes(wl.hp, wl.cp, n_occ, "raycast")
     achieved = alg_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(prof):
-        try:
-            with open(prof) as f:
-                tj = json.load(f)
-            traffic = tj.get(args.config, {}).get(dominant)
-        except Exception:
-            traffic = None
+    moved = 36.0 * W * H  # depth, depth4, colours: the normal map is left to computeNormals, which rewrites all of it
     roofline = dict(bound="hbm", kernel="k_render (raycast)", achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
-                    algorithmic_bytes=alg_bytes, avg_launch_us=round(dom_us, 3), event_pair_us=round(pair_us, 3),
+                    frac=round(achieved / HBM_PEAK_GBS, 6),
+                    traffic=None, traffic_note="PMC counters are collected in separate rocprofv3 passes: profiles/README.md holds the measured HBM bytes of this kernel",
+                    algorithmic_bytes=alg_bytes, algorithmic_bytes_rule="SURVEY.md 8(d): 52*W*H, the four output maps of renderKernel",
+                    bytes_stored_by_launch=moved, frac_of_bytes_stored=round(moved / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6) if dom_us > 0 else 0.0,
+                    avg_launch_us=round(dom_us, 3), event_pair_us=round(pair_us, 3),
                     event_pair_overhead_us=round(overhead_us, 3), launches_timed=launches, event_stride=wl.event_stride,
-                    stage_us_warmup={k: round(v, 3) for k, v in stage_us.items()}, blocks_in_frustum=n_occ)
-    per_launch_us = stage_us
+                    dominant_stage_of_warmup=dominant,
+                    second_bound=dict(bound="valu issue (not a contract field)", note="DESIGN.md section 6: wave instructions x issue cycles / SIMDs / clock + the kernel's fixed cost"),
+                    stage_us_warmup={k: round(v, 3) for k, v in stage_us.items()}, stage_frames=n_stage, blocks_in_frustum=n_occ)
+    rooflines = {}
+    if stage_us.get("integrate", 0.0) > 0.0:
+        kus = stage_us["integrate"] - (overhead_us if 0.0 < overhead_us < 0.5 * stage_us["integrate"] else 0.0)
+        rooflines["integrate"] = integrate_roofline(kus, n_occ, wl.hp, wl.cp, f"{args.config} ({wl.cfg['scene']}), steady state of the warm-up")
 
     result = None
     if rank == 0:
         cfg = wl.cfg
+        stream_note = ""
+        if wl.streaming:
+            stream_note = "stream out/in per frame + "
         result = {
-            "metric": "depth frames/sec integrate+raycast @640x480, 4 cm voxel; HBM GB/s vs peak",
+            "metric": METRIC,
             "value": round(value, 3),
             "unit": "frames/s",
             "n_gpus": world,
@@ -314,21 +532,87 @@ def main():
             "config": {
                 "workload": f"{args.config}: {cfg['scene']} orbit, {cfg['width']}x{cfg['height']}, {cfg['params']} voxels, "
                             f"{cfg['num_buckets']} buckets, {cfg['num_sdf_blocks']} SDF blocks, "
-                            f"alloc+compactify+integrate+{'gc+' if not args.no_gc else ''}raycast+normals per frame",
+                            f"{stream_note}alloc+compactify+integrate+{'gc+' if not args.no_gc else ''}raycast+normals per frame",
                 "alloc_mode": "offline (fixed point)" if args.offline else "online (one pass per frame)",
                 "streams": "one independent scene per GPU",
+                "frame_loop": "python (2 ctypes calls per frame)" if args.python_loop else "native (vh_reconstruction_run: one call for all frames)",
+                "alloc_ahead": not args.no_alloc_ahead and not wl.streaming and not args.python_loop,
+                "frames_in_flight": args.frames_in_flight,
+                "preroll_frames": preroll_frames,
             },
+            "host_enqueue_us_per_frame": round(host_enqueue_us, 3),
+            "host_wait_us_per_frame": round(host_wait_us, 3),
             "roofline": roofline,
+            "rooflines": rooflines,
         }
+        if wl.streaming:
+            result["streaming"] = dict(blocks_out=int(st1["blocksStreamedOut"] - st0["blocksStreamedOut"]),
+                                       blocks_in=int(st1["blocksStreamedIn"] - st0["blocksStreamedIn"]),
+                                       blocks_per_second=round((st1["blocksStreamedOut"] - st0["blocksStreamedOut"] + st1["blocksStreamedIn"] - st0["blocksStreamedIn"]) / elapsed, 1))
+    wl.close()
+    del wl
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        # 1. the integrate kernel where it can fill the machine: camera inside a 3 m sphere (S2), 1 cm voxels
+        try:
+            n = 48
+            dl = GpuWorkload("cfg3", n, 0, args, scene="S2", streaming=False)
+            dl.set_event_stride(1)
+            dl.run(0, n - 16)
+            dus = dl.stage_sample(n - 16, n)
+            docc = dl.scene.getNumOccupiedBlocks()
+            oh = 1e3 * dl.ray.getEventPairOverheadMs()
+            kus = dus["integrate"] - (oh if 0.0 < oh < 0.5 * dus["integrate"] else 0.0)
+            result["rooflines"]["integrate_dense"] = integrate_roofline(kus, docc, dl.hp, dl.cp, "cfg3 tables, scene S2 (every pixel valid), 1 cm voxels, no streaming; 16 frames")
+            result["rooflines"]["integrate_dense"]["stage_us"] = {k: round(v, 3) for k, v in dus.items()}
+            dl.close()
+            del dl
+            torch.cuda.empty_cache()
+        except Exception as e:
+            result["rooflines"]["integrate_dense"] = dict(failed=str(e))
+        # 2. the same loop fed from the host: float depth + RGBX bytes in pinned memory, uploaded on a copy stream
+        try:
+            hw, hs = min(args.warmup, 20), min(args.steps, 300)
+            hl = GpuWorkload(args.config, hw + hs, 0, args, frames_on_host=True)
+            hl.set_event_stride(1 << 30)
+            hl.run(0, hw)
+            hl.recon.synchronize()
+            torch.cuda.synchronize()
+            h0 = hl.recon.getStats()
+            t0 = time.perf_counter()
+            hl.run(hw, hw + hs)
+            hl.recon.synchronize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            h1 = hl.recon.getStats()
+            ups = max(h1["uploadsTimed"] - h0["uploadsTimed"], 1)
+            result["value_with_upload"] = round(hs / dt, 3)
+            result["upload"] = dict(frames=hs, upload_us=round(1e3 * (h1["uploadMs"] - h0["uploadMs"]) / ups, 3), bytes_per_frame=int(h1["uploadBytes"]),
+                                    how="pinned host frames (float depth + RGBX colour), hipMemcpyAsync on a copy stream into two staging slots, "
+                                        "colour converted on the device; the upload of frame k+1 runs beside frame k")
+            hl.close()
+            del hl
+            torch.cuda.empty_cache()
+        except Exception as e:
+            result["value_with_upload"] = None
+            result["upload"] = dict(failed=str(e))
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_frames, args)
             except Exception as e:  # the baseline must never sink the GPU result
                 result["cpu_baseline"] = dict(value=None, unit="frames/s", cores=1, kind="port", sample=f"failed: {e}")
+            if not args.no_extra_legs:
+                try:
+                    result["cfg1"] = cfg1_leg(args)
+                except Exception as e:
+                    result["cfg1"] = dict(failed=str(e))
         else:
             result["cpu_baseline"] = None
         if args.stages:
-            print(json.dumps(per_launch_us), file=sys.stderr)
+            print(json.dumps(stage_us), file=sys.stderr)
         print(json.dumps(result), flush=True)
     if dist_mod is not None:
         dist_mod.barrier()
@@ -337,4 +621,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    r = main()
+    sys.exit(r if isinstance(r, int) else 0)

@@ -26,6 +26,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "vh_api.h"
@@ -102,6 +103,17 @@ public:
     void debugHash(unsigned int report[4] = nullptr);
 
     // additions
+    // The two halves of integrate() for a frame loop that knows the pose of a frame before it ray-casts the previous
+    // one (a recorded trajectory: s_binaryDumpSensorUseTrajectory, DSC/DepthSensing.cpp:733-747).  integrateAhead()
+    // enqueues alloc + compactify on a side stream of the scene, ordered behind everything the main stream holds at
+    // the call; integrateFinish() makes the main stream wait for them and enqueues the pass over the voxels.  What the
+    // main stream receives between the two calls (CUDARayCastSDF::render of the previous pose) runs beside alloc +
+    // compactify and leaves the same maps: a block allocated meanwhile holds only unobserved voxels (weight 0), which
+    // a sample treats exactly like an absent block.  Offline mode and the reference launch
+    // sequence need their blocking read-backs: there integrateAhead() only remembers its arguments.
+    void integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& depthCameraData,
+                        const DepthCameraParams& depthCameraParams, const unsigned int* d_bitMask);
+    void integrateFinish(const DepthCameraData& depthCameraData, const DepthCameraParams& depthCameraParams);
     void setOptions(const VhSceneOptions& o) { m_options = o; }
     const VhSceneOptions& getOptions() const { return m_options; }
     vhStream_t getStream() const { return m_stream; }
@@ -113,8 +125,9 @@ public:
 private:
     void create(const HashParams& params);
     void destroy();
-    void alloc(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask); // :247
-    void compactifyHashEntries(const DepthCameraParams&);                                        // :282
+    void alloc(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask, vhStream_t stream); // :247
+    void compactifyHashEntries(const DepthCameraParams&, vhStream_t stream);                                        // :282
+    void integrateFused(const DepthCameraData&, const DepthCameraParams&);
     void integrateDepthMap(const DepthCameraData&, const DepthCameraParams&);                    // :317
     void garbageCollect(const DepthCameraParams&);                                               // :327
     void pollOccupiedCount(bool block);
@@ -130,6 +143,12 @@ private:
     bool m_occupiedPending;   // a frame was enqueued since the host value was last known exact
     bool m_counterCleared;    // d_hashCompactifiedCounter is known to be 0 (k_alloc clears it)
     VhStageTimer* m_timer;
+    vhStream_t m_sideStream;  // integrateAhead(): alloc + compactify run here
+    void* m_aheadEvents[8];   // hipEvent_t ring: {main -> side, side -> main} of the last four frames
+    unsigned int m_aheadSlot;
+    int m_aheadPending;       // 0 none, 1 alloc + compactify enqueued on the side stream, 2 arguments remembered only
+    vh::mat4f m_aheadTransform;
+    const unsigned int* m_aheadBitMask;
 };
 
 // ---------------------------------------------------------------------------
@@ -249,6 +268,8 @@ public:
     void saveToFile(const std::string& filename, const vh::vec3f& camPos, float radius);
     void loadFromFile(const std::string& filename, const vh::vec3f& camPos, float radius);
 
+    unsigned int getNumStreamedOutBlocks() const { return s_nStreamdOutBlocks; } // of the last pass 0
+    unsigned int getNumStreamedInBlocks() const { return s_nStreamdInBlocks; }   // of the last pass 1
     const vh::vec3f& getPosCamera() const { return s_posCamera; }
     float getRadius() const { return s_radius; }
     bool getTerminatedThread() const { return s_terminateThread; }
@@ -326,6 +347,52 @@ private:
     CUDASceneRepHashSDF* m_sceneRepHashSDF;
 };
 
+
+// ---------------------------------------------------------------------------
+// The frame loop: reconstruction() of DSC/DepthSensing.cpp:720-924 for a recorded sequence at given poses, as a
+// class over the three host classes above (the reference keeps them in globals: g_sceneRep, g_rayCast, g_chunkGrid).
+typedef VhReconstructionOptions ReconstructionOptions;
+typedef VhSequenceFrame SequenceFrame;
+typedef VhReconstructionStats ReconstructionStats;
+
+class Reconstruction {
+public:
+    Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* rayCast, CUDASceneRepChunkGrid* chunkGrid,
+                   const DepthCameraParams& depthCameraParams, const ReconstructionOptions& options);
+    ~Reconstruction();
+    Reconstruction(const Reconstruction&) = delete;
+    Reconstruction& operator=(const Reconstruction&) = delete;
+
+    static ReconstructionOptions defaultOptions();
+    void run(const SequenceFrame* frames, unsigned int n);
+    void synchronize();
+    void reset();
+    const ReconstructionStats& getStats();
+
+private:
+    void frame(const SequenceFrame& f);
+    DepthCameraData upload(const SequenceFrame& f);
+
+    CUDASceneRepHashSDF* m_sceneRep;
+    CUDARayCastSDF* m_rayCast;
+    CUDASceneRepChunkGrid* m_chunkGrid;
+    DepthCameraParams m_cp;
+    ReconstructionOptions m_opt;
+    ReconstructionStats m_stats;
+    unsigned int m_frameNumber;
+    // run-ahead bound: one event per frame in a ring
+    std::vector<void*> m_frameDone;
+    // frames on the host: two staging slots fed by a copy stream
+    void* m_copyStream;
+    float* d_stageDepth[2];
+    unsigned char* d_stageColorRaw[2];
+    float* d_stageColor[2];
+    void* m_slotReady[2]; // copy stream -> main stream
+    void* m_slotFree[2];  // main stream -> copy stream
+    bool m_slotUsed[2];
+    std::vector<std::pair<void*, void*>> m_uploadTimers; // event pairs on the copy stream, not yet read
+    std::vector<void*> m_timerPool;
+};
 
 // ---------------------------------------------------------------------------
 // CUDAMarchingCubesHashSDF (DSC/CUDAMarchingCubesHashSDF.h:8-67, .cpp:16-224): iso-surface extraction of the

@@ -129,6 +129,9 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
  * deals them to the workgroups so that the compute units get even loads.  The maps do not depend on it, and a render
  * whose splat was given no schedule uses raster order. */
 size_t vh_render_schedule_bytes(uint32_t width, uint32_t height);
+/* how many tiles of an image of this size a scheduled render marches with two waves each (the dearest ones; 0 for
+ * small images): lets a test make sure it exercises that path */
+uint32_t vh_render_split_tiles(uint32_t width, uint32_t height);
 int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
                         const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
                         uint32_t* d_schedule, uint32_t phase, vhStream_t stream);
@@ -203,6 +206,12 @@ int vh_scene_rep_get_state(VhSceneRep* s, uint32_t* out);
 int vh_scene_rep_get_timings(VhSceneRep* s, double out[4]);
 int vh_scene_rep_set_options(VhSceneRep* s, const VhSceneOptions* opt);
 
+/* integrateAhead / integrateFinish: the two halves of integrate() (include/vh.hpp); what the scene's stream receives
+ * between them runs beside alloc + compactify */
+int vh_scene_rep_integrate_ahead(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraData* cam,
+                                 const VhDepthCameraParams* cp, const uint32_t* d_bitMask);
+int vh_scene_rep_integrate_finish(VhSceneRep* s, const VhDepthCameraData* cam, const VhDepthCameraParams* cp);
+
 /* CUDARayCastSDF(const RayCastParams&) :16 */
 int vh_raycast_create(const VhRayCastParams* rp, vhStream_t stream, VhRayCast** out);
 void vh_raycast_destroy(VhRayCast* r);
@@ -257,6 +266,24 @@ int vh_chunk_grid_download_host_blocks(VhChunkGrid* g, VhSDFBlockDesc* descs, Vh
 /* saveToFile / loadFromFile (.hashgrid v1) DSC/CUDASceneRepChunkGrid.h:459-548 */
 int vh_chunk_grid_save_to_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
 int vh_chunk_grid_load_from_file(VhChunkGrid* g, const char* filename, const float camPos[3], float radius);
+
+/* ---- the frame loop: reconstruction(), DSC/DepthSensing.cpp:720-924, headless over a recorded sequence at given
+ * poses ("build's headless vh_bench / vh_replay driver").  Per frame, in the reference's order:
+ * render(pose of the previous frame) -> [stream out / stream in around the camera] -> integrate(pose, depth, colour,
+ * bit mask).  One call enqueues any number of frames; nothing in it waits for the device unless streaming is on (its
+ * read-backs) or the run-ahead bound is reached.  The scene, the ray caster and the chunk grid stay the caller's. */
+typedef struct VhReconstruction VhReconstruction;
+void vh_reconstruction_default_options(VhReconstructionOptions* out);
+int vh_reconstruction_create(VhSceneRep* scene, VhRayCast* rayCast, VhChunkGrid* chunkGrid /* may be NULL */,
+                             const VhDepthCameraParams* cp, const VhReconstructionOptions* opt, VhReconstruction** out);
+void vh_reconstruction_destroy(VhReconstruction* r);
+/* processes frames[0..n): frame numbers continue from the previous call (the first frame of all is not ray-cast) */
+int vh_reconstruction_run(VhReconstruction* r, const VhSequenceFrame* frames, uint32_t n);
+/* waits for everything the loop has enqueued (all its streams) */
+int vh_reconstruction_synchronize(VhReconstruction* r);
+int vh_reconstruction_get_stats(VhReconstruction* r, VhReconstructionStats* out);
+/* frame counter and statistics back to zero (the scene is the caller's to reset) */
+int vh_reconstruction_reset(VhReconstruction* r);
 
 /* ---- sensor pre-processing: the image kernels of DSC/CameraUtil.cu that CUDARGBDAdapter::process
  * (DSC/CUDARGBDAdapter.cpp:93-137) and CUDARGBDSensor::process (DSC/CUDARGBDSensor.cpp:147-257) run on every frame.

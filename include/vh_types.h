@@ -212,6 +212,44 @@ typedef struct VhSceneOptions {
     uint32_t s_streamingOutParts;
 } VhSceneOptions;
 
+/* The switches reconstruction() reads (DSC/DepthSensing.cpp:720-924) when it runs headless over a recorded sequence at
+ * given poses (s_binaryDumpSensorUseTrajectory = true, s_binaryDumpSensorUseTrajectoryOnlyInit = false), plus what is
+ * not in the reference: how far the host may run ahead of the device, and where the frames live. */
+typedef struct VhReconstructionOptions {
+    uint8_t s_streamingEnabled;   /* :881-900: stream out / in around the camera every frame (needs a chunk grid) */
+    uint8_t s_integrationEnabled; /* :903-908: 0 = setLastRigidTransformAndCompactify instead of integrate */
+    uint8_t s_offlineProcessing;  /* :885-891: streaming moves every part out and everything in range in, each frame */
+    uint8_t s_renderEnabled;      /* 0 = skip the ray cast of the previous pose (:763) */
+    uint8_t s_allocAhead;         /* not in the reference: alloc + compactify of frame k run beside the ray cast of pose
+                                     k-1 (CUDASceneRepHashSDF::integrateAhead); ignored while streaming is on */
+    uint8_t s_framesOnHost;       /* not in the reference: VhSequenceFrame pointers are HOST memory (pinned for an
+                                     asynchronous copy): float depth + RGBX bytes as a sensor delivers them
+                                     (RGBDSensor::getDepthFloat / getColorRGBX); uploaded on a copy stream into two
+                                     staging slots, beside the previous frame's work */
+    uint8_t pad0[2];
+    uint32_t s_maxFramesInFlight; /* frames the host may enqueue ahead of the device (0 = no bound) */
+    float s_streamingPos[3];      /* DSC/DepthSensing.cpp:1340-1355: in camera space */
+    float s_streamingRadius;
+} VhReconstructionOptions;
+
+/* one frame of a recorded sequence */
+typedef struct VhSequenceFrame {
+    float rigidTransform[16]; /* camera-to-world pose of the trajectory; [0] = -inf or NaN marks an invalid frame (:738) */
+    const float* depth;       /* width*height floats (device pointer, or host pointer with s_framesOnHost) */
+    const void* color;        /* device: float4 per pixel (may be NULL); host: RGBX bytes, 4 per pixel */
+} VhSequenceFrame;
+
+typedef struct VhReconstructionStats {
+    uint64_t frames;             /* frames processed since creation / reset */
+    uint64_t invalidFrames;      /* skipped: invalid pose */
+    uint64_t blocksStreamedOut, blocksStreamedIn;
+    double hostEnqueueSeconds;   /* host time inside run() spent enqueueing work (waits for the device excluded) */
+    double hostWaitSeconds;      /* host time inside run() spent waiting: run-ahead bound, streaming read-backs */
+    double uploadMs;             /* device time of the timed frame uploads (copy stream, HIP events) */
+    uint64_t uploadsTimed;
+    uint64_t uploadBytes;        /* bytes per frame upload */
+} VhReconstructionStats;
+
 /* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt
  * file by vh_app_state_read.  A key the file does not hold is value-initialised (0 / false), as readMembers() does
  * (DSC/GlobalAppState.h:139-142). */

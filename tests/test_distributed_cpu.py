@@ -40,3 +40,33 @@ def test_two_rank_weak_scaling_harness():
     assert a[2] == b[2] == warmup + steps       # every rank ran its own frames
     assert a[1] > 10 and b[1] > 10              # both reconstructed something
     assert a[0] != b[0]                          # phase-shifted orbits: different scenes
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) starts two ranks itself, before
+    anything touches a GPU, and relays rank 0's line: n_gpus = 2 and the whole-job frame count.  --standin replaces
+    the GPU workload by a CPU delay (this container has no GPU); the launch path, the rendezvous, the barriers and
+    the reductions are bench.py's own."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--standin"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["scaling"] == "weak"
+    # two ranks x 5 frames of 2 ms each, timed as the slower rank: 10 frames in >= 10 ms
+    assert 0 < res["value"] <= 2 * 5 / 0.010 + 1
+    assert "STANDIN" in res["data"]
+
+
+def test_a_failing_rank_fails_the_launch():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # without --standin a rank needs a GPU: on this machine every rank exits with an error, and so must the launcher
+    import torch
+    if torch.cuda.is_available():
+        return
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0

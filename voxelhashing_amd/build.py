@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvoxelhashing_amd.so")
-SOURCES = ["vh_kernels.hip", "vh_host.cpp", "vh_chunk_grid.cpp", "vh_marching_cubes.cpp", "vh_sensor.cpp", "vh_sensor_data.cpp", "vh_params.cpp", "vh_tracking.cpp", "vh_c_api.cpp"]
-HEADERS = ["vh_device.hpp", "vh_host_util.hpp", "vh_stage_timer.hpp",
+SOURCES = ["vh_kernels.hip", "vh_host.cpp", "vh_chunk_grid.cpp", "vh_marching_cubes.cpp", "vh_sensor.cpp", "vh_sensor_data.cpp", "vh_params.cpp", "vh_tracking.cpp", "vh_reconstruction.cpp", "vh_c_api.cpp"]
+HEADERS = ["vh_device.hpp", "vh_host_util.hpp", "vh_stage_timer.hpp", "vh_handles.hpp",
            os.path.join(ROOT, "include", "vh_types.h"), os.path.join(ROOT, "include", "vh_api.h"),
            os.path.join(ROOT, "include", "vh.hpp"), os.path.join(ROOT, "include", "vh_mc_tables.h")]
 ARCH = "gfx950"
@@ -48,15 +48,27 @@ def build(force=False, verbose=False, extra=()):
     if not force and up_to_date():
         return LIB
     cc = hipcc()
+    lib_t = os.path.getmtime(LIB) if os.path.exists(LIB) else 0.0
+    hdr_t = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+    jobs = []
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [cc] + flags() + list(extra) + ["-c", src, "-o", obj]
+        objs.append(obj)
+        # an object is reused when it is newer than its source and every header (and no extra flags are given)
+        if not force and not extra and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            continue
+        jobs.append([cc] + flags() + list(extra) + ["-c", src, "-o", obj])
+    procs = []
+    for cmd in jobs:  # the translation units compile side by side (the kernels' one takes the longest)
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)

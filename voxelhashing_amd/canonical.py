@@ -22,6 +22,13 @@ def lexsort_pos(pos):
     return np.lexsort((pos[:, 2], pos[:, 1], pos[:, 0]))
 
 
+def block_positions(hash_table):
+    """sorted positions of the allocated blocks of a hash table"""
+    occ = hash_table["ptr"] != T.FREE_ENTRY
+    pos = np.ascontiguousarray(hash_table["pos"][occ])
+    return pos[lexsort_pos(pos)]
+
+
 def snapshot(hash_table, sdf_blocks, heap, heap_counter, hp, with_voxels=True):
     occ = hash_table["ptr"] != T.FREE_ENTRY
     idx = np.nonzero(occ)[0]

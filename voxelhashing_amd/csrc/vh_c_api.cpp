@@ -1,46 +1,14 @@
 // vh_c_api.cpp -- handle-level C ABI over the C++ host classes (include/vh.hpp):
 // what an FFI binding (ctypes, cgo, JNI ...) of the reference's host-class
 // interface would call.  Exceptions become error codes here.
-#include <hip/hip_runtime.h>
+#include "vh_handles.hpp"
 
-#include <cstring>
-#include <new>
-
-#include "../../include/vh.hpp"
-
-struct VhSceneRep { CUDASceneRepHashSDF impl; VhSceneRep(const HashParams& p, const VhSceneOptions& o, vhStream_t s) : impl(p, o, s) {} };
-struct VhRayCast { CUDARayCastSDF impl; VhRayCast(const RayCastParams& p, vhStream_t s) : impl(p, s) {} };
-struct VhMarchingCubes { CUDAMarchingCubesHashSDF impl; VhMarchingCubes(const MarchingCubesParams& p, vhStream_t s) : impl(p, s) {} };
-struct VhRGBDSensor { CUDARGBDSensor impl; VhRGBDSensor(const CUDARGBDSensor::Config& c, vhStream_t s) : impl(c, s) {} };
-struct VhSensorData { vh::SensorData impl; };
-struct VhSensorDataReader { vh::SensorDataReader impl; };
-struct VhCameraTracking { CUDACameraTrackingMultiRes impl; VhCameraTracking(unsigned int w, unsigned int h, unsigned int l, vhStream_t s) : impl(w, h, l, s) {} };
-struct VhChunkGrid {
-    CUDASceneRepChunkGrid impl;
-    VhChunkGrid(CUDASceneRepHashSDF* s, const vh::vec3f& e, const vh::vec3i& d, const vh::vec3i& m, unsigned int l, bool en, unsigned int parts)
-        : impl(s, e, d, m, l, en, parts) {}
-};
+char* vh_last_error_buffer() { extern thread_local char vh_g_lastError[512]; return vh_g_lastError; }
+thread_local char vh_g_lastError[512] = "";
 
 namespace {
 
-thread_local char g_lastError[512] = "";
-
-template <class F> int guarded(F&& f)
-{
-    try {
-        f();
-        return VH_OK;
-    } catch (const vh::Error& e) {
-        std::strncpy(g_lastError, e.what(), sizeof(g_lastError) - 1);
-        return e.code ? e.code : VH_ERR_BAD_ARGUMENT;
-    } catch (const std::bad_alloc&) {
-        std::strncpy(g_lastError, "out of host memory", sizeof(g_lastError) - 1);
-        return -(int)hipErrorOutOfMemory;
-    } catch (const std::exception& e) {
-        std::strncpy(g_lastError, e.what(), sizeof(g_lastError) - 1);
-        return VH_ERR_BAD_ARGUMENT;
-    }
-}
+template <class F> int guarded(F&& f) { return vh_guarded(static_cast<F&&>(f)); }
 
 inline vh::mat4f toMat(const float m[16])
 {
@@ -54,7 +22,7 @@ inline vh::vec3f toVec(const float v[3]) { return { v[0], v[1], v[2] }; }
 
 extern "C" {
 
-const char* vh_last_error_message(void) { return g_lastError; }
+const char* vh_last_error_message(void) { return vh_g_lastError; }
 
 // ---- CUDASceneRepHashSDF ----------------------------------------------------
 
@@ -74,6 +42,17 @@ int vh_scene_rep_integrate(VhSceneRep* s, const float rigidTransform[16], const 
 {
     if (!s || !rigidTransform || !cam || !cp) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { s->impl.integrate(toMat(rigidTransform), *cam, *cp, d_bitMask); });
+}
+int vh_scene_rep_integrate_ahead(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraData* cam,
+                                 const VhDepthCameraParams* cp, const uint32_t* d_bitMask)
+{
+    if (!s || !rigidTransform || !cam || !cp) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.integrateAhead(toMat(rigidTransform), *cam, *cp, d_bitMask); });
+}
+int vh_scene_rep_integrate_finish(VhSceneRep* s, const VhDepthCameraData* cam, const VhDepthCameraParams* cp)
+{
+    if (!s || !cam || !cp) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { s->impl.integrateFinish(*cam, *cp); });
 }
 int vh_scene_rep_set_last_rigid_transform_and_compactify(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraParams* cp)
 {

@@ -285,6 +285,15 @@ VHD int lookup_ptr(const VhHashData& hd, const VhHashParams& hp, I3 blk)
     while (maxIter < hp.m_hashMaxCollisionLinkedListSize) {
         int4 q = load_quad(&hd.d_hash[i]);
         if (quad_matches(q, blk)) return q.w;
+        if (q.w == VH_FREE_ENTRY && i != idxLast) {
+            // A list never holds a free entry.  This one is a copy from before an alloc_block that runs beside this
+            // kernel (CUDASceneRepHashSDF::integrateAhead) put a new head here: it stores the entry, fences, then
+            // stores the link that led here, so the entry is in memory; drop this compute unit's stale lines and
+            // read it again (what follows the new head is the list as it was).
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            q = load_quad(&hd.d_hash[i]);
+            if (quad_matches(q, blk)) return q.w;
+        }
         uint32_t off = hd.d_hash[i].offset;
         if (off == 0) break;
         i = (idxLast + off) % ne;
@@ -372,6 +381,9 @@ VHD int alloc_block(const VhHashData& hd, const VhHashParams& hp, I3 pos, int32_
                     VhHashEntry* e = &hd.d_hash[i];
                     e->offset = lastOffset;
                     store_quad(e, make_int4(pos.x, pos.y, pos.z, (int)(blk * VH_SDF_BLOCK_VOXELS)));
+                    // the new head is in memory before the link to it: a ray caster that runs beside this pass
+                    // (integrateAhead) and follows the link finds the entry (lookup_ptr)
+                    __threadfence();
                     hd.d_hash[idxLast].offset = (uint32_t)offset;
                     bucket_inc(hd, i);
                     return 1;

@@ -281,6 +281,11 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
     m_occupiedPending = false;
     m_counterCleared = false;
     m_timer = new VhStageTimer(3);
+    m_sideStream = nullptr;
+    for (void*& e : m_aheadEvents) e = nullptr;
+    m_aheadSlot = 0;
+    m_aheadPending = 0;
+    m_aheadBitMask = nullptr;
     std::memset(&m_hashData, 0, sizeof(m_hashData));
     check(vh_hash_data_alloc(&m_hashData, &m_hashParams), "HashData::allocate");
     // mapped pinned word the fused integrate kernel mirrors the in-frustum block count into
@@ -294,9 +299,13 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
 
 void CUDASceneRepHashSDF::destroy()
 {
+    if (m_sideStream) (void)hipStreamSynchronize((hipStream_t)m_sideStream);
     (void)hipStreamSynchronize((hipStream_t)m_stream);
     delete m_timer;
     m_timer = nullptr;
+    for (void*& e : m_aheadEvents)
+        if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+    if (m_sideStream) { (void)hipStreamDestroy((hipStream_t)m_sideStream); m_sideStream = nullptr; }
     if (h_occupied) (void)hipHostFree(h_occupied);
     vh_hash_data_free(&m_hashData);
 }
@@ -308,6 +317,8 @@ void CUDASceneRepHashSDF::reset()
     const vh::mat4f id = vh::mat4f::identity();
     std::memcpy(m_hashParams.m_rigidTransform, id.m, sizeof(id.m));
     std::memcpy(m_hashParams.m_rigidTransformInverse, id.m, sizeof(id.m));
+    if (m_sideStream) checkHip(hipStreamSynchronize((hipStream_t)m_sideStream), "hipStreamSynchronize");
+    m_aheadPending = 0;
     pollOccupiedCount(true);
     *h_occupied = 0;
     m_hashParams.m_numOccupiedBlocks = 0;
@@ -338,7 +349,7 @@ void CUDASceneRepHashSDF::setLastRigidTransform(const vh::mat4f& t)
 void CUDASceneRepHashSDF::setLastRigidTransformAndCompactify(const vh::mat4f& t, const DepthCameraParams& cp)
 {
     setLastRigidTransform(t);
-    compactifyHashEntries(cp);
+    compactifyHashEntries(cp, m_stream);
 }
 
 const vh::mat4f CUDASceneRepHashSDF::getLastRigidTransform() const
@@ -388,69 +399,123 @@ unsigned int CUDASceneRepHashSDF::getHeapFreeCount()
 void CUDASceneRepHashSDF::integrate(const vh::mat4f& lastRigidTransform, const DepthCameraData& cam,
                                     const DepthCameraParams& cp, const unsigned int* d_bitMask)
 {
+    if (m_aheadPending) throw vh::Error(VH_ERR_BAD_ARGUMENT, "integrate(): integrateAhead() is waiting for its integrateFinish()");
     setLastRigidTransform(lastRigidTransform);
-    alloc(cam, cp, d_bitMask);
-    compactifyHashEntries(cp);
+    alloc(cam, cp, d_bitMask, m_stream);
+    compactifyHashEntries(cp, m_stream);
     if (m_options.s_useReferenceLaunchSequence) {
         integrateDepthMap(cam, cp);
         garbageCollect(cp);
     } else {
-        // integrate -> [starve] -> identify -> free in one pass over the voxels
-        uint32_t flags = 0;
-        if (m_options.s_garbageCollectionEnabled) {
-            flags |= VH_FUSED_GC;
-            if (m_numIntegratedFrames > 0 && m_options.s_garbageCollectionStarve != 0 &&
-                m_numIntegratedFrames % m_options.s_garbageCollectionStarve == 0)
-                flags |= VH_FUSED_STARVE;
-        }
-        const bool timed = m_options.s_timingsDetailledEnabled;
-        if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
-        check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), (uint32_t*)m_occupiedEvent, m_stream), "integrate (fused)");
-        m_occupiedPending = true;
-        if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
+        integrateFused(cam, cp);
     }
     m_numIntegratedFrames++;
 }
 
+// integrate -> [starve] -> identify -> free in one pass over the voxels
+void CUDASceneRepHashSDF::integrateFused(const DepthCameraData& cam, const DepthCameraParams& cp)
+{
+    uint32_t flags = 0;
+    if (m_options.s_garbageCollectionEnabled) {
+        flags |= VH_FUSED_GC;
+        if (m_numIntegratedFrames > 0 && m_options.s_garbageCollectionStarve != 0 &&
+            m_numIntegratedFrames % m_options.s_garbageCollectionStarve == 0)
+            flags |= VH_FUSED_STARVE;
+    }
+    const bool timed = m_options.s_timingsDetailledEnabled;
+    if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
+    check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), (uint32_t*)m_occupiedEvent, m_stream), "integrate (fused)");
+    m_occupiedPending = true;
+    if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
+}
+
+// first half of integrate() on the side stream (see include/vh.hpp)
+void CUDASceneRepHashSDF::integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& cam,
+                                         const DepthCameraParams& cp, const unsigned int* d_bitMask)
+{
+    if (m_aheadPending) throw vh::Error(VH_ERR_BAD_ARGUMENT, "integrateAhead(): the previous one has not been finished");
+    if (m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence) {
+        m_aheadTransform = lastRigidTransform;
+        m_aheadBitMask = d_bitMask;
+        m_aheadPending = 2;
+        return;
+    }
+    if (!m_sideStream) {
+        hipStream_t s = nullptr;
+        checkHip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        m_sideStream = (vhStream_t)s;
+        for (void*& e : m_aheadEvents) {
+            hipEvent_t ev = nullptr;
+            checkHip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            e = (void*)ev;
+        }
+    }
+    setLastRigidTransform(lastRigidTransform);
+    m_aheadSlot = (m_aheadSlot + 2u) % 8u;
+    hipEvent_t toSide = (hipEvent_t)m_aheadEvents[m_aheadSlot], toMain = (hipEvent_t)m_aheadEvents[m_aheadSlot + 1u];
+    // behind everything the main stream holds now: the previous frame's pass over the voxels (its garbage collection
+    // edits the table) and whatever produced this frame's depth map
+    checkHip(hipEventRecord(toSide, (hipStream_t)m_stream), "hipEventRecord");
+    checkHip(hipStreamWaitEvent((hipStream_t)m_sideStream, toSide, 0), "hipStreamWaitEvent");
+    alloc(cam, cp, d_bitMask, m_sideStream);
+    compactifyHashEntries(cp, m_sideStream);
+    checkHip(hipEventRecord(toMain, (hipStream_t)m_sideStream), "hipEventRecord");
+    m_aheadPending = 1;
+}
+
+void CUDASceneRepHashSDF::integrateFinish(const DepthCameraData& cam, const DepthCameraParams& cp)
+{
+    if (!m_aheadPending) throw vh::Error(VH_ERR_BAD_ARGUMENT, "integrateFinish() without integrateAhead()");
+    if (m_aheadPending == 2) {
+        m_aheadPending = 0;
+        integrate(m_aheadTransform, cam, cp, m_aheadBitMask);
+        return;
+    }
+    m_aheadPending = 0;
+    checkHip(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_aheadEvents[m_aheadSlot + 1u], 0), "hipStreamWaitEvent");
+    integrateFused(cam, cp);
+    m_numIntegratedFrames++;
+}
+
 // DSC/CUDASceneRepHashSDF.h:247-279
-void CUDASceneRepHashSDF::alloc(const DepthCameraData& cam, const DepthCameraParams& cp, const unsigned int* d_bitMask)
+void CUDASceneRepHashSDF::alloc(const DepthCameraData& cam, const DepthCameraParams& cp, const unsigned int* d_bitMask, vhStream_t stream)
 {
     const bool timed = m_options.s_timingsDetailledEnabled;
-    if (timed) m_timer->start(ST_ALLOC, (hipStream_t)m_stream);
+    if (timed) m_timer->start(ST_ALLOC, (hipStream_t)stream);
     if (m_options.s_offlineProcessing) {
         // allocate until all blocks are allocated (one blocking read-back per pass, as the reference)
         unsigned int prevFree = getHeapFreeCount();
         while (true) {
-            check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), m_stream), "allocCUDA");
+            check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), stream), "allocCUDA");
             unsigned int currFree = getHeapFreeCount();
             if (prevFree != currFree) prevFree = currFree;
             else break;
         }
     } else {
-        check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), m_stream), "allocCUDA");
+        check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), stream), "allocCUDA");
     }
     m_counterCleared = true; // k_alloc clears d_hashCompactifiedCounter
-    if (timed) m_timer->stop(ST_ALLOC, (hipStream_t)m_stream);
+    if (timed) m_timer->stop(ST_ALLOC, (hipStream_t)stream);
 }
 
 // DSC/CUDASceneRepHashSDF.h:282-315
-void CUDASceneRepHashSDF::compactifyHashEntries(const DepthCameraParams& cp)
+void CUDASceneRepHashSDF::compactifyHashEntries(const DepthCameraParams& cp, vhStream_t stream)
 {
     const bool timed = m_options.s_timingsDetailledEnabled;
-    if (timed) m_timer->start(ST_COMPACTIFY, (hipStream_t)m_stream);
+    if (timed) m_timer->start(ST_COMPACTIFY, (hipStream_t)stream);
     const bool needHostCount = m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence;
     // alloc() leaves the counter cleared; the stand-alone path (setLastRigidTransformAndCompactify) must clear it
     const uint32_t flags = m_counterCleared ? VH_COMPACT_COUNTER_IS_ZERO : 0u;
     m_counterCleared = false;
     if (needHostCount) {
         uint32_t n = 0;
-        check(vh_compactify(&m_hashData, &m_hashParams, &cp, &n, flags, m_stream), "compactifyHashAllInOneCUDA");
+        check(vh_compactify(&m_hashData, &m_hashParams, &cp, &n, flags, stream), "compactifyHashAllInOneCUDA");
         m_hashParams.m_numOccupiedBlocks = n;
         m_occupiedPending = false;
     } else {
-        check(vh_compactify(&m_hashData, &m_hashParams, &cp, nullptr, flags, m_stream), "compactifyHashAllInOneCUDA");
+        check(vh_compactify(&m_hashData, &m_hashParams, &cp, nullptr, flags, stream), "compactifyHashAllInOneCUDA");
     }
-    if (timed) m_timer->stop(ST_COMPACTIFY, (hipStream_t)m_stream);
+    if (timed) m_timer->stop(ST_COMPACTIFY, (hipStream_t)stream);
 }
 
 // DSC/CUDASceneRepHashSDF.h:317-325
@@ -483,6 +548,7 @@ void CUDASceneRepHashSDF::getState(uint32_t out[VH_STATE_WORDS])
 
 void CUDASceneRepHashSDF::getTimings(double out[4])
 {
+    if (m_sideStream) checkHip(hipStreamSynchronize((hipStream_t)m_sideStream), "hipStreamSynchronize");
     m_timer->resolve((hipStream_t)m_stream);
     out[0] = m_timer->totalMs[ST_ALLOC];
     out[1] = m_timer->totalMs[ST_COMPACTIFY];

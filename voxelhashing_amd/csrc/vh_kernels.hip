@@ -2536,6 +2536,8 @@ size_t vh_render_schedule_bytes(uint32_t width, uint32_t height)
     return (4u + 4u * ((tiles + 3u) / 4u) + 2u * 4u * ((tiles + kSplitTiles + 3u) / 4u)) * sizeof(uint32_t);
 }
 
+uint32_t vh_render_split_tiles(uint32_t width, uint32_t height) { return split_tiles(cdiv(width, 8) * cdiv(height, 8)); }
+
 int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
                         const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
                         uint32_t* d_schedule, uint32_t phase, vhStream_t stream)

@@ -1,0 +1,318 @@
+// vh_reconstruction.cpp -- the frame loop of the reference application, reconstruction()
+// (DSC/DepthSensing.cpp:720-924), for a recorded sequence at given poses, behind the C ABI: one host call enqueues any
+// number of frames (the build's headless driver).  DSC/ = /root/reference/DepthSensingCUDA/Source/.
+//
+// Per frame, in the reference's order:
+//   render(pose of the previous frame)                         :750-763
+//   [stream out around the camera; stream in]                  :881-900
+//   integrate(pose, depth, colour, bit mask)                   :903
+// What is not in the reference:
+//   * s_allocAhead: the pose of frame k is known before pose k-1 is ray-cast (it comes from the file), so alloc +
+//     compactify of frame k are enqueued first, on the scene's side stream, and run beside the ray cast;
+//   * s_framesOnHost: float depth + RGBX colour in host memory (what RGBDSensor::getDepthFloat / getColorRGBX hand
+//     to CUDARGBDAdapter::process, DSC/CUDARGBDAdapter.cpp:107-131) are uploaded on a copy stream into one of two
+//     staging slots, beside the previous frame's work, and the colour is converted there (convertColorRawToFloat4);
+//   * s_maxFramesInFlight: the host stays at most that many frames ahead of the device.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "vh_handles.hpp"
+#include "vh_host_util.hpp"
+
+namespace {
+
+inline void check(int code, const char* what)
+{
+    if (code != 0) throw vh::Error(code, std::string(what) + ": " + vh_error_string(code));
+}
+inline void checkHip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw vh::Error(-(int)e, std::string(what) + ": " + hipGetErrorString(e));
+}
+inline double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline hipEvent_t newEvent(bool timing)
+{
+    hipEvent_t e = nullptr;
+    checkHip(timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    return e;
+}
+
+} // namespace
+
+ReconstructionOptions Reconstruction::defaultOptions()
+{
+    ReconstructionOptions o;
+    std::memset(&o, 0, sizeof(o));
+    o.s_streamingEnabled = 0;
+    o.s_integrationEnabled = 1;
+    o.s_offlineProcessing = 0;
+    o.s_renderEnabled = 1;
+    o.s_allocAhead = 1;
+    o.s_framesOnHost = 0;
+    o.s_maxFramesInFlight = 16;
+    o.s_streamingPos[0] = o.s_streamingPos[1] = 0.0f;
+    o.s_streamingPos[2] = 3.0f; // zParametersDefault.txt: s_streamingPos
+    o.s_streamingRadius = 4.0f;
+    return o;
+}
+
+Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* rayCast, CUDASceneRepChunkGrid* chunkGrid,
+                               const DepthCameraParams& cp, const ReconstructionOptions& options)
+    : m_sceneRep(sceneRep), m_rayCast(rayCast), m_chunkGrid(chunkGrid), m_cp(cp), m_opt(options), m_frameNumber(0), m_copyStream(nullptr)
+{
+    if (!sceneRep) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: no scene");
+    if (options.s_streamingEnabled && !chunkGrid) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: streaming needs a chunk grid");
+    if (options.s_renderEnabled && !rayCast) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: rendering needs a ray caster");
+    std::memset(&m_stats, 0, sizeof(m_stats));
+    for (int i = 0; i < 2; i++) {
+        d_stageDepth[i] = nullptr; d_stageColorRaw[i] = nullptr; d_stageColor[i] = nullptr;
+        m_slotReady[i] = m_slotFree[i] = nullptr;
+        m_slotUsed[i] = false;
+    }
+    if (m_opt.s_maxFramesInFlight) {
+        m_frameDone.resize(m_opt.s_maxFramesInFlight, nullptr);
+        for (void*& e : m_frameDone) e = (void*)newEvent(false);
+    }
+    if (m_opt.s_framesOnHost) {
+        const size_t n = (size_t)cp.m_imageWidth * cp.m_imageHeight;
+        hipStream_t cs = nullptr;
+        checkHip(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
+        m_copyStream = (void*)cs;
+        for (int i = 0; i < 2; i++) {
+            checkHip(hipMalloc((void**)&d_stageDepth[i], sizeof(float) * (n ? n : 1)), "staging depth");
+            checkHip(hipMalloc((void**)&d_stageColorRaw[i], 4 * (n ? n : 1)), "staging colour (raw)");
+            checkHip(hipMalloc((void**)&d_stageColor[i], sizeof(float) * 4 * (n ? n : 1)), "staging colour");
+            m_slotReady[i] = (void*)newEvent(false);
+            m_slotFree[i] = (void*)newEvent(false);
+        }
+        m_stats.uploadBytes = (sizeof(float) + 4) * n;
+    }
+}
+
+Reconstruction::~Reconstruction()
+{
+    try { synchronize(); } catch (...) {}
+    for (void* e : m_frameDone)
+        if (e) (void)hipEventDestroy((hipEvent_t)e);
+    for (auto& p : m_uploadTimers) { (void)hipEventDestroy((hipEvent_t)p.first); (void)hipEventDestroy((hipEvent_t)p.second); }
+    for (void* e : m_timerPool) (void)hipEventDestroy((hipEvent_t)e);
+    for (int i = 0; i < 2; i++) {
+        if (m_slotReady[i]) (void)hipEventDestroy((hipEvent_t)m_slotReady[i]);
+        if (m_slotFree[i]) (void)hipEventDestroy((hipEvent_t)m_slotFree[i]);
+        if (d_stageDepth[i]) (void)hipFree(d_stageDepth[i]);
+        if (d_stageColorRaw[i]) (void)hipFree(d_stageColorRaw[i]);
+        if (d_stageColor[i]) (void)hipFree(d_stageColor[i]);
+    }
+    if (m_copyStream) (void)hipStreamDestroy((hipStream_t)m_copyStream);
+}
+
+void Reconstruction::synchronize()
+{
+    if (m_copyStream) checkHip(hipStreamSynchronize((hipStream_t)m_copyStream), "hipStreamSynchronize");
+    // the scene's side stream joins the main stream in integrateFinish(): the main stream is the last to finish
+    checkHip(hipStreamSynchronize((hipStream_t)m_sceneRep->getStream()), "hipStreamSynchronize");
+}
+
+void Reconstruction::reset()
+{
+    synchronize();
+    (void)getStats(); // returns the pending timer events to the pool
+    const uint64_t bytes = m_stats.uploadBytes;
+    std::memset(&m_stats, 0, sizeof(m_stats));
+    m_stats.uploadBytes = bytes;
+    m_frameNumber = 0;
+    m_slotUsed[0] = m_slotUsed[1] = false;
+}
+
+const ReconstructionStats& Reconstruction::getStats()
+{
+    if (!m_uploadTimers.empty()) {
+        checkHip(hipStreamSynchronize((hipStream_t)m_copyStream), "hipStreamSynchronize");
+        for (auto& p : m_uploadTimers) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, (hipEvent_t)p.first, (hipEvent_t)p.second) == hipSuccess) { m_stats.uploadMs += ms; m_stats.uploadsTimed++; }
+            m_timerPool.push_back(p.first);
+            m_timerPool.push_back(p.second);
+        }
+        m_uploadTimers.clear();
+    }
+    return m_stats;
+}
+
+// CUDARGBDAdapter::process :107-131 for a frame at adapter resolution: upload, colour bytes -> float4
+DepthCameraData Reconstruction::upload(const SequenceFrame& f)
+{
+    const unsigned int slot = m_frameNumber & 1u;
+    const size_t n = (size_t)m_cp.m_imageWidth * m_cp.m_imageHeight;
+    hipStream_t cs = (hipStream_t)m_copyStream, ms = (hipStream_t)m_sceneRep->getStream();
+    // the slot is free once the frame that used it last has been integrated
+    if (m_slotUsed[slot]) checkHip(hipStreamWaitEvent(cs, (hipEvent_t)m_slotFree[slot], 0), "hipStreamWaitEvent");
+    auto timerEvent = [&]() {
+        if (!m_timerPool.empty()) { void* e = m_timerPool.back(); m_timerPool.pop_back(); return e; }
+        return (void*)newEvent(true);
+    };
+    void* t0 = timerEvent();
+    void* t1 = timerEvent();
+    checkHip(hipEventRecord((hipEvent_t)t0, cs), "hipEventRecord");
+    checkHip(hipMemcpyAsync(d_stageDepth[slot], f.depth, sizeof(float) * n, hipMemcpyHostToDevice, cs), "upload depth");
+    if (f.color) checkHip(hipMemcpyAsync(d_stageColorRaw[slot], f.color, 4 * n, hipMemcpyHostToDevice, cs), "upload colour");
+    checkHip(hipEventRecord((hipEvent_t)t1, cs), "hipEventRecord");
+    m_uploadTimers.emplace_back(t0, t1);
+    if (f.color) check(vh_convert_color_raw_to_float4(d_stageColor[slot], d_stageColorRaw[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "convertColorRawToFloat4");
+    checkHip(hipEventRecord((hipEvent_t)m_slotReady[slot], cs), "hipEventRecord");
+    checkHip(hipStreamWaitEvent(ms, (hipEvent_t)m_slotReady[slot], 0), "hipStreamWaitEvent");
+    m_slotUsed[slot] = true;
+    DepthCameraData cam;
+    std::memset(&cam, 0, sizeof(cam));
+    cam.d_depthData = d_stageDepth[slot];
+    cam.d_colorData = f.color ? d_stageColor[slot] : nullptr;
+    return cam;
+}
+
+void Reconstruction::frame(const SequenceFrame& f)
+{
+    // :733-747
+    vh::mat4f transformation;
+    std::memcpy(transformation.m, f.rigidTransform, sizeof(transformation.m));
+    if (transformation.m[0] == -std::numeric_limits<float>::infinity() || std::isnan(transformation.m[0])) {
+        m_stats.invalidFrames++;
+        return; // "INVALID FRAME"
+    }
+    if (!f.depth) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: frame without a depth map");
+
+    DepthCameraData cam;
+    if (m_opt.s_framesOnHost) cam = upload(f);
+    else {
+        std::memset(&cam, 0, sizeof(cam));
+        cam.d_depthData = const_cast<float*>(f.depth);
+        cam.d_colorData = const_cast<float*>(static_cast<const float*>(f.color));
+    }
+
+    const bool streaming = m_opt.s_streamingEnabled && m_chunkGrid;
+    const bool ahead = m_opt.s_allocAhead && m_opt.s_integrationEnabled && !streaming;
+    // :750-751 (the pose the scene holds is the previous frame's)
+    const vh::mat4f renderTransform = m_sceneRep->getLastRigidTransform();
+    if (ahead) m_sceneRep->integrateAhead(transformation, cam, m_cp, nullptr);
+    if (m_frameNumber > 0 && m_opt.s_renderEnabled) // :750 "getFrameNumber() > 1" with frames counted from 1
+        m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform); // :763
+
+    const unsigned int* d_bitMask = nullptr;
+    if (streaming) { // :881-900
+        const double t0 = now();
+        const vh::vec3f p = transformation.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
+        unsigned int nStreamedBlocks = 0;
+        if (m_opt.s_offlineProcessing) {
+            for (unsigned int i = 0; i < m_sceneRep->getOptions().s_streamingOutParts; i++) {
+                m_chunkGrid->streamOutToCPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
+                m_stats.blocksStreamedOut += nStreamedBlocks;
+            }
+            m_chunkGrid->streamInToGPUAll(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
+            m_stats.blocksStreamedIn += nStreamedBlocks;
+        } else {
+            const bool threaded = !m_chunkGrid->getTerminatedThread();
+            if (threaded) {
+                m_chunkGrid->streamOutToCPUPass0GPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, true);
+                m_stats.blocksStreamedOut += m_chunkGrid->getNumStreamedOutBlocks();
+                m_chunkGrid->streamInToGPUPass1GPU(true);
+                m_stats.blocksStreamedIn += m_chunkGrid->getNumStreamedInBlocks();
+            } else {
+                m_chunkGrid->streamOutToCPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
+                m_stats.blocksStreamedOut += nStreamedBlocks;
+                m_chunkGrid->streamInToGPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
+                m_stats.blocksStreamedIn += nStreamedBlocks;
+            }
+        }
+        d_bitMask = m_chunkGrid->getBitMaskGPU();
+        m_stats.hostWaitSeconds += now() - t0; // read-backs of the streaming counters: the host waits for the device here
+    }
+
+    if (m_opt.s_integrationEnabled) { // :903
+        if (ahead) m_sceneRep->integrateFinish(cam, m_cp);
+        else m_sceneRep->integrate(transformation, cam, m_cp, d_bitMask);
+    } else {
+        m_sceneRep->setLastRigidTransformAndCompactify(transformation, m_cp); // :907
+    }
+    if (m_opt.s_framesOnHost)
+        checkHip(hipEventRecord((hipEvent_t)m_slotFree[m_frameNumber & 1u], (hipStream_t)m_sceneRep->getStream()), "hipEventRecord");
+    m_frameNumber++;
+    m_stats.frames++;
+}
+
+void Reconstruction::run(const SequenceFrame* frames, unsigned int n)
+{
+    if (n && !frames) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction::run: null frames");
+    const double t0 = now();
+    double waited = 0.0;
+    const double streamWait0 = m_stats.hostWaitSeconds;
+    const unsigned int ring = (unsigned int)m_frameDone.size();
+    for (unsigned int i = 0; i < n; i++) {
+        if (ring && m_frameNumber >= ring) { // the frame that used this event `ring` frames ago must be done
+            const double w0 = now();
+            checkHip(hipEventSynchronize((hipEvent_t)m_frameDone[m_frameNumber % ring]), "hipEventSynchronize");
+            waited += now() - w0;
+        }
+        const unsigned int number = m_frameNumber;
+        frame(frames[i]);
+        if (ring && m_frameNumber != number)
+            checkHip(hipEventRecord((hipEvent_t)m_frameDone[number % ring], (hipStream_t)m_sceneRep->getStream()), "hipEventRecord");
+    }
+    const double total = now() - t0, streamWait = m_stats.hostWaitSeconds - streamWait0;
+    m_stats.hostWaitSeconds += waited;
+    m_stats.hostEnqueueSeconds += total - waited - streamWait;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+namespace {
+template <class F> int guarded(F&& f) { return vh_guarded(static_cast<F&&>(f)); }
+} // namespace
+
+extern "C" {
+
+void vh_reconstruction_default_options(VhReconstructionOptions* out)
+{
+    if (out) *out = Reconstruction::defaultOptions();
+}
+
+int vh_reconstruction_create(VhSceneRep* scene, VhRayCast* rayCast, VhChunkGrid* chunkGrid, const VhDepthCameraParams* cp,
+                             const VhReconstructionOptions* opt, VhReconstruction** out)
+{
+    if (!scene || !cp || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    return guarded([&] {
+        const ReconstructionOptions o = opt ? *opt : Reconstruction::defaultOptions();
+        *out = new VhReconstruction(&scene->impl, rayCast ? &rayCast->impl : nullptr, chunkGrid ? &chunkGrid->impl : nullptr, *cp, o);
+    });
+}
+void vh_reconstruction_destroy(VhReconstruction* r) { delete r; }
+int vh_reconstruction_run(VhReconstruction* r, const VhSequenceFrame* frames, uint32_t n)
+{
+    if (!r || (n && !frames)) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.run(frames, n); });
+}
+int vh_reconstruction_synchronize(VhReconstruction* r)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.synchronize(); });
+}
+int vh_reconstruction_get_stats(VhReconstruction* r, VhReconstructionStats* out)
+{
+    if (!r || !out) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { *out = r->impl.getStats(); });
+}
+int vh_reconstruction_reset(VhReconstruction* r)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.reset(); });
+}
+
+} // extern "C"

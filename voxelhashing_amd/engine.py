@@ -90,6 +90,15 @@ class CUDASceneRepHashSDF:
         check(self.L.vh_scene_rep_integrate(self.handle, f16(lastRigidTransform), C.byref(data), C.byref(depthCameraParams), d_bitMask),
               "CUDASceneRepHashSDF::integrate")
 
+    def integrateAhead(self, lastRigidTransform, depthCameraData, depthCameraParams, d_bitMask=None):
+        data = depthCameraData.data if isinstance(depthCameraData, DepthFrame) else depthCameraData
+        check(self.L.vh_scene_rep_integrate_ahead(self.handle, f16(lastRigidTransform), C.byref(data), C.byref(depthCameraParams), d_bitMask),
+              "CUDASceneRepHashSDF::integrateAhead")
+
+    def integrateFinish(self, depthCameraData, depthCameraParams):
+        data = depthCameraData.data if isinstance(depthCameraData, DepthFrame) else depthCameraData
+        check(self.L.vh_scene_rep_integrate_finish(self.handle, C.byref(data), C.byref(depthCameraParams)), "CUDASceneRepHashSDF::integrateFinish")
+
     def setLastRigidTransformAndCompactify(self, lastRigidTransform, depthCameraParams):
         check(self.L.vh_scene_rep_set_last_rigid_transform_and_compactify(self.handle, f16(lastRigidTransform), C.byref(depthCameraParams)),
               "setLastRigidTransformAndCompactify")
@@ -327,6 +336,74 @@ class CUDASceneRepChunkGrid:
 
     def loadFromFile(self, filename, camPos, radius):
         check(self.L.vh_chunk_grid_load_from_file(self.handle, filename.encode(), f16(camPos), radius), "loadFromFile")
+
+
+class Reconstruction:
+    """The frame loop reconstruction() (DepthSensingCUDA/Source/DepthSensing.cpp:720-924) for a recorded sequence at
+    given poses, native behind the C ABI: run() enqueues any number of frames with one call."""
+
+    def __init__(self, sceneRep, rayCast, chunkGrid, depthCameraParams, options=None):
+        self.L = load()
+        self.scene, self.ray, self.grid = sceneRep, rayCast, chunkGrid  # kept alive as long as the loop
+        self._cp = _copy_struct(depthCameraParams)
+        self._options = _copy_struct(options) if options is not None else self.defaultOptions()
+        h = C.c_void_p()
+        check(self.L.vh_reconstruction_create(sceneRep.handle, rayCast.handle if rayCast is not None else None,
+                                              chunkGrid.handle if chunkGrid is not None else None, C.byref(self._cp),
+                                              C.byref(self._options), C.byref(h)), "vh_reconstruction_create")
+        self.handle = h
+
+    @staticmethod
+    def defaultOptions(**overrides):
+        o = T.ReconstructionOptions()
+        load().vh_reconstruction_default_options(C.byref(o))
+        for k, v in overrides.items():
+            if k in ("s_streamingPos",):
+                o.s_streamingPos[:] = [float(x) for x in v]
+            else:
+                setattr(o, k, v)
+        return o
+
+    @staticmethod
+    def makeFrames(poses, depth_ptrs, color_ptrs):
+        """-> ctypes array of VhSequenceFrame (device pointers, or host pointers for s_framesOnHost)"""
+        n = len(poses)
+        arr = (T.SequenceFrame * n)()
+        for k in range(n):
+            arr[k].rigidTransform[:] = [float(v) for v in np.asarray(poses[k], dtype=np.float32).reshape(-1)]
+            arr[k].depth = depth_ptrs[k]
+            arr[k].color = color_ptrs[k] if color_ptrs is not None else None
+        return arr
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vh_reconstruction_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, frames, first=0, count=None):
+        """frames: a VhSequenceFrame array (makeFrames); processes frames[first:first+count]"""
+        n = len(frames) - first if count is None else count
+        if n <= 0:
+            return
+        ptr = C.cast(C.byref(frames, first * C.sizeof(T.SequenceFrame)), C.POINTER(T.SequenceFrame))
+        check(self.L.vh_reconstruction_run(self.handle, ptr, n), "Reconstruction::run")
+
+    def synchronize(self):
+        check(self.L.vh_reconstruction_synchronize(self.handle), "Reconstruction::synchronize")
+
+    def reset(self):
+        check(self.L.vh_reconstruction_reset(self.handle), "Reconstruction::reset")
+
+    def getStats(self):
+        st = T.ReconstructionStats()
+        check(self.L.vh_reconstruction_get_stats(self.handle, C.byref(st)), "Reconstruction::getStats")
+        return {k: getattr(st, k) for k, _ in T.ReconstructionStats._fields_}
 
 
 class LauncherScene:

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "vh_ray_interval_splat": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP]),
     "vh_render_intervals": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP]),
     "vh_render_schedule_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "vh_render_split_tiles": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
     "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "vh_scene_rep_get_state": (C.c_int, [_VP, P(C.c_uint32)]),
     "vh_scene_rep_get_timings": (C.c_int, [_VP, P(C.c_double)]),
     "vh_scene_rep_set_options": (C.c_int, [_VP, P(T.SceneOptions)]),
+    "vh_scene_rep_integrate_ahead": (C.c_int, [_VP, _F16, P(T.DepthCameraData), P(T.DepthCameraParams), _VP]),
+    "vh_scene_rep_integrate_finish": (C.c_int, [_VP, P(T.DepthCameraData), P(T.DepthCameraParams)]),
     "vh_raycast_create": (C.c_int, [P(T.RayCastParams), _VP, P(_VP)]),
     "vh_raycast_destroy": (None, [_VP]),
     "vh_raycast_render": (C.c_int, [_VP, P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _F16]),
@@ -80,6 +83,13 @@ PROTOTYPES = {
     "vh_raycast_set_timing": (C.c_int, [_VP, C.c_int]),
     "vh_raycast_set_timing_stride": (C.c_int, [_VP, C.c_int, C.c_uint32]),
     "vh_raycast_set_interval_splatting": (C.c_int, [_VP, C.c_int]),
+    "vh_reconstruction_default_options": (None, [P(T.ReconstructionOptions)]),
+    "vh_reconstruction_create": (C.c_int, [_VP, _VP, _VP, P(T.DepthCameraParams), P(T.ReconstructionOptions), P(_VP)]),
+    "vh_reconstruction_destroy": (None, [_VP]),
+    "vh_reconstruction_run": (C.c_int, [_VP, P(T.SequenceFrame), C.c_uint32]),
+    "vh_reconstruction_synchronize": (C.c_int, [_VP]),
+    "vh_reconstruction_get_stats": (C.c_int, [_VP, P(T.ReconstructionStats)]),
+    "vh_reconstruction_reset": (C.c_int, [_VP]),
     "vh_convert_color_raw_to_float4": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_resample_float_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_resample_float4_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP]),

@@ -206,6 +206,39 @@ class SceneOptions(C.Structure):
     ]
 
 
+class ReconstructionOptions(C.Structure):
+    _fields_ = [
+        ("s_streamingEnabled", C.c_uint8),
+        ("s_integrationEnabled", C.c_uint8),
+        ("s_offlineProcessing", C.c_uint8),
+        ("s_renderEnabled", C.c_uint8),
+        ("s_allocAhead", C.c_uint8),
+        ("s_framesOnHost", C.c_uint8),
+        ("pad0", C.c_uint8 * 2),
+        ("s_maxFramesInFlight", C.c_uint32),
+        ("s_streamingPos", C.c_float * 3),
+        ("s_streamingRadius", C.c_float),
+    ]
+
+
+class SequenceFrame(C.Structure):
+    _fields_ = [("rigidTransform", C.c_float * 16), ("depth", C.c_void_p), ("color", C.c_void_p)]
+
+
+class ReconstructionStats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64),
+        ("invalidFrames", C.c_uint64),
+        ("blocksStreamedOut", C.c_uint64),
+        ("blocksStreamedIn", C.c_uint64),
+        ("hostEnqueueSeconds", C.c_double),
+        ("hostWaitSeconds", C.c_double),
+        ("uploadMs", C.c_double),
+        ("uploadsTimed", C.c_uint64),
+        ("uploadBytes", C.c_uint64),
+    ]
+
+
 assert C.sizeof(HashEntry) == 32
 assert C.sizeof(Voxel) == 8
 assert C.sizeof(HashParams) == 224
