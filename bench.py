@@ -52,7 +52,7 @@ def parse_args(argv=None):
     p.add_argument("--cpu-frames", type=int, default=40, help="frames of the workload timed on the CPU oracle")
     p.add_argument("--stages", action="store_true", help="also print per-stage device times to stderr")
     p.add_argument("--scene", default=None, help="override the scene (S1, S2)")
-    p.add_argument("--event-stride", type=int, default=0, help="HIP events around k_render on every n-th timed frame (0: 1 below 64 steps, else 8)")
+    p.add_argument("--event-stride", type=int, default=0, help="HIP events around k_render on every n-th timed frame (0: steps/10, at most 8)")
     p.add_argument("--no-alloc-ahead", action="store_true", help="alloc + compactify on the main stream, behind the ray cast")
     p.add_argument("--no-streaming", action="store_true", help="cfg3 without its per-frame stream out / stream in")
     p.add_argument("--frames-in-flight", type=int, default=16, help="frames the host may run ahead of the device (0: no bound)")
@@ -454,7 +454,8 @@ def main(argv=None):
 
     n_frames = args.warmup + args.steps
     wl = GpuWorkload(args.config, n_frames, rank, args)
-    stride = args.event_stride if args.event_stride > 0 else (1 if args.steps < 64 else 8)
+    # at least 8-10 pairs behind avg_launch_us, but not a pair around every launch: a record idles the queue for ~6 us
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(8, args.steps // 10))
     wl.set_event_stride(stride)
 
     # untimed pre-roll (set-up): the device is busy with this workload's own kernels before anything is measured

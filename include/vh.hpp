@@ -105,15 +105,18 @@ public:
     // additions
     // The two halves of integrate() for a frame loop that knows the pose of a frame before it ray-casts the previous
     // one (a recorded trajectory: s_binaryDumpSensorUseTrajectory, DSC/DepthSensing.cpp:733-747).  integrateAhead()
-    // enqueues alloc + compactify on a side stream of the scene, ordered behind everything the main stream holds at
-    // the call; integrateFinish() makes the main stream wait for them and enqueues the pass over the voxels.  What the
-    // main stream receives between the two calls (CUDARayCastSDF::render of the previous pose) runs beside alloc +
-    // compactify and leaves the same maps: a block allocated meanwhile holds only unobserved voxels (weight 0), which
-    // a sample treats exactly like an absent block.  Offline mode and the reference launch
-    // sequence need their blocking read-backs: there integrateAhead() only remembers its arguments.
-    void integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& depthCameraData,
-                        const DepthCameraParams& depthCameraParams, const unsigned int* d_bitMask);
+    // sets the pose and returns the frame's alloc + compactify passes as a job; CUDARayCastSDF::render(..., job)
+    // launches them INSIDE its own two launches (the alloc pass behind the ray caster's workgroups, where it fills the
+    // tail the dearest tiles leave; the compactify pass behind computeNormals'); integrateFinish() launches whatever
+    // of the job is still open and then the pass over the voxels.  The maps stay the same: a block allocated while
+    // rays are marched holds only unobserved voxels (weight 0), which a sample treats exactly like an absent block
+    // (DESIGN.md section 3).  Offline mode and the reference launch sequence need their blocking read-backs: there the
+    // job is never handed out.
+    VhFrameJob* integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& depthCameraData,
+                               const DepthCameraParams& depthCameraParams, const unsigned int* d_bitMask);
     void integrateFinish(const DepthCameraData& depthCameraData, const DepthCameraParams& depthCameraParams);
+    // frames whose pass over the voxels has started on the device (read from mapped host memory: no synchronisation)
+    unsigned int getNumFramesStartedOnDevice() const;
     void setOptions(const VhSceneOptions& o) { m_options = o; }
     const VhSceneOptions& getOptions() const { return m_options; }
     vhStream_t getStream() const { return m_stream; }
@@ -125,8 +128,8 @@ public:
 private:
     void create(const HashParams& params);
     void destroy();
-    void alloc(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask, vhStream_t stream); // :247
-    void compactifyHashEntries(const DepthCameraParams&, vhStream_t stream);                                        // :282
+    void alloc(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask, bool jobPrepared); // :247
+    void compactifyHashEntries(const DepthCameraParams&);                                        // :282
     void integrateFused(const DepthCameraData&, const DepthCameraParams&);
     void integrateDepthMap(const DepthCameraData&, const DepthCameraParams&);                    // :317
     void garbageCollect(const DepthCameraParams&);                                               // :327
@@ -138,17 +141,16 @@ private:
     vhStream_t m_stream;
     unsigned int m_numIntegratedFrames;
     int32_t m_lockEpoch;
-    uint32_t* h_occupied;     // mapped pinned word: the fused integrate kernel mirrors the block count here
+    uint32_t* h_occupied;     // mapped pinned words: the fused integrate kernel mirrors {block count, frame number} here
     void* m_occupiedEvent;    // device alias of h_occupied
     bool m_occupiedPending;   // a frame was enqueued since the host value was last known exact
     bool m_counterCleared;    // d_hashCompactifiedCounter is known to be 0 (k_alloc clears it)
     VhStageTimer* m_timer;
-    vhStream_t m_sideStream;  // integrateAhead(): alloc + compactify run here
-    void* m_aheadEvents[8];   // hipEvent_t ring: {main -> side, side -> main} of the last four frames
-    unsigned int m_aheadSlot;
-    int m_aheadPending;       // 0 none, 1 alloc + compactify enqueued on the side stream, 2 arguments remembered only
-    vh::mat4f m_aheadTransform;
-    const unsigned int* m_aheadBitMask;
+    VhFrameJob m_job;         // alloc + compactify of the frame in progress
+    int m_aheadPending;       // 0 none, 1 job prepared by integrateAhead()
+    void* d_packedFrame;      // the frame as the alloc pass packs it for the pass over the voxels (8 bytes per pixel)
+    size_t m_packedPixels;
+    void prepareJob(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask);
 };
 
 // ---------------------------------------------------------------------------
@@ -162,8 +164,10 @@ public:
     // DSC/CUDARayCastSDF.cpp:38-72.  The reference skips the view-matrix
     // update while hashParams.m_numOccupiedBlocks == 0 (stale matrices); here
     // the given transform is always used.
+    // coLaunch (not in the reference): a job of CUDASceneRepHashSDF::integrateAhead, whose alloc and compactify
+    // passes then ride in this call's two launches
     void render(const HashData& hashData, const HashParams& hashParams, const DepthCameraParams& cameraParams,
-                const vh::mat4f& lastRigidTransform);
+                const vh::mat4f& lastRigidTransform, VhFrameJob* coLaunch = nullptr);
     const RayCastData& getRayCastData() { return m_data; }        // :42
     const RayCastParams& getRayCastParams() const { return m_params; } // :45
 
@@ -380,8 +384,6 @@ private:
     ReconstructionOptions m_opt;
     ReconstructionStats m_stats;
     unsigned int m_frameNumber;
-    // run-ahead bound: one event per frame in a ring
-    std::vector<void*> m_frameDone;
     // frames on the host: two staging slots fed by a copy stream
     void* m_copyStream;
     float* d_stageDepth[2];

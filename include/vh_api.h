@@ -94,9 +94,17 @@ int vh_bind_input_depth_color_textures(const VhDepthCameraData* cam);
  * The block count is read on the device from d_hashCompactifiedCounter; if d_countMirror != NULL
  * (a device pointer, e.g. of mapped pinned host memory) the count is also stored there. */
 enum { VH_FUSED_GC = 1, VH_FUSED_STARVE = 2 };
+/* d_countMirror (may be NULL) receives two words: the block count and `mirrorTag`, a number of the caller's choice
+ * (the host class passes its frame counter: a host that maps the words can follow the device without an event).
+ * d_packedFrame (may be NULL): the frame as vh_alloc_job packed it, 8 bytes per pixel {depth, colour bytes + sample
+ * weight}; the pass then gathers 8 bytes per voxel instead of 20 from the depth and colour maps (same results). */
 int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
                        const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, uint32_t* d_countMirror,
-                       vhStream_t stream);
+                       uint32_t mirrorTag, const void* d_packedFrame, vhStream_t stream);
+/* the alloc / compactify pass of a prepared frame (VhFrameJob, vh_types.h); vh_alloc_job also packs the frame into
+ * job->d_packedFrame when that is not NULL.  Each marks the job. */
+int vh_alloc_job(VhFrameJob* job, vhStream_t stream);
+int vh_compactify_job(VhFrameJob* job, vhStream_t stream);
 
 /* ---- ray-cast launchers: DSC/CUDARayCastSDF.cpp:10-21 ----------------------- */
 /* renderCS(const HashData&, const RayCastData&, const DepthCameraData&, const RayCastParams&)
@@ -137,6 +145,14 @@ int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRa
                         uint32_t* d_schedule, uint32_t phase, vhStream_t stream);
 /* computeNormals(float4* d_output, float4* d_input, width, height)  DSC/CameraUtil.cu:699 */
 int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream);
+/* The same two launches with the passes of a frame job riding along as extra workgroups (job may be NULL, or already
+ * launched: then they equal the plain calls): the alloc pass behind the ray caster's workgroups, where it fills the
+ * tail the dearest tiles leave, and the compactify pass behind computeNormals'.  Legal because a block allocated while
+ * rays are marched holds only unobserved voxels, which a sample treats like an absent block. */
+int vh_render_intervals_co(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
+                           const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                           uint32_t* d_schedule, uint32_t phase, VhFrameJob* job, vhStream_t stream);
+int vh_compute_normals_co(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* job, vhStream_t stream);
 
 /* ---- streaming launchers: DSC/CUDASceneRepChunkGrid.h:142-146 --------------- */
 /* integrateFromGlobalHashPass1CUDA(params, hashData, threadsPerPart, start, radius, camPos,
@@ -206,10 +222,11 @@ int vh_scene_rep_get_state(VhSceneRep* s, uint32_t* out);
 int vh_scene_rep_get_timings(VhSceneRep* s, double out[4]);
 int vh_scene_rep_set_options(VhSceneRep* s, const VhSceneOptions* opt);
 
-/* integrateAhead / integrateFinish: the two halves of integrate() (include/vh.hpp); what the scene's stream receives
- * between them runs beside alloc + compactify */
+/* integrateAhead / integrateFinish: the two halves of integrate() (include/vh.hpp).  *job receives the frame's alloc +
+ * compactify passes for vh_raycast_render_co (NULL when the scene's options rule a co-launch out); it belongs to the
+ * scene and is valid until vh_scene_rep_integrate_finish */
 int vh_scene_rep_integrate_ahead(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraData* cam,
-                                 const VhDepthCameraParams* cp, const uint32_t* d_bitMask);
+                                 const VhDepthCameraParams* cp, const uint32_t* d_bitMask, VhFrameJob** job);
 int vh_scene_rep_integrate_finish(VhSceneRep* s, const VhDepthCameraData* cam, const VhDepthCameraParams* cp);
 
 /* CUDARayCastSDF(const RayCastParams&) :16 */
@@ -218,6 +235,9 @@ void vh_raycast_destroy(VhRayCast* r);
 /* render(hashData, hashParams, cameraData, lastRigidTransform), DSC/CUDARayCastSDF.cpp:38 */
 int vh_raycast_render(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp,
                       const VhDepthCameraParams* cp, const float lastRigidTransform[16]);
+/* the same with a frame job riding along (may be NULL) */
+int vh_raycast_render_co(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp,
+                         const VhDepthCameraParams* cp, const float lastRigidTransform[16], VhFrameJob* job);
 /* getRayCastData() :42 / getRayCastParams() :45 */
 int vh_raycast_get_data(VhRayCast* r, VhRayCastData* out);
 int vh_raycast_get_params(VhRayCast* r, VhRayCastParams* out);
@@ -290,6 +310,10 @@ int vh_reconstruction_reset(VhReconstruction* r);
  * Device pointers; float4 maps are passed as float* (4 per pixel); MINF marks an invalid pixel.  The filters read
  * their whole neighbourhood, so they do not work in place. */
 int vh_convert_color_raw_to_float4(float* d_output4, const uint8_t* d_inputRGBX, uint32_t width, uint32_t height, vhStream_t stream); /* :154 */
+/* not in the reference: a sensor frame read by a kernel straight from pinned, device-visible host memory (the pointers
+ * as hipHostGetDevicePointer returns them): depth copied, RGBX colour converted to float4 on the way.  width*height
+ * must be a multiple of 4.  hostRGBX / d_color4 may be NULL. */
+int vh_upload_frame(const float* hostDepth, const uint8_t* hostRGBX, float* d_depth, float* d_color4, uint32_t width, uint32_t height, vhStream_t stream);
 int vh_resample_float_map(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const float* d_input,
                           uint32_t inputWidth, uint32_t inputHeight, vhStream_t stream);                                       /* :1120 */
 int vh_resample_float4_map(float* d_output4, uint32_t outputWidth, uint32_t outputHeight, const float* d_input4,

@@ -212,6 +212,20 @@ typedef struct VhSceneOptions {
     uint32_t s_streamingOutParts;
 } VhSceneOptions;
 
+/* alloc + compactify of one frame as a job (CUDASceneRepHashSDF::integrateAhead prepares it): whoever holds it may
+ * launch the two passes -- CUDARayCastSDF::render does so INSIDE its own two launches (vh_render_intervals_co,
+ * vh_compute_normals_co), CUDASceneRepHashSDF::integrateFinish launches whatever is still open. */
+typedef struct VhFrameJob {
+    VhHashData hashData;
+    VhHashParams hashParams; /* with the frame's pose */
+    VhDepthCameraData cam;
+    VhDepthCameraParams cp;
+    const uint32_t* d_bitMask;
+    void* d_packedFrame;     /* width*height*8 bytes, written by the alloc pass (see vh_alloc_job), or NULL */
+    int32_t lockToken;
+    uint8_t allocLaunched, compactifyLaunched, pad0[2];
+} VhFrameJob;
+
 /* The switches reconstruction() reads (DSC/DepthSensing.cpp:720-924) when it runs headless over a recorded sequence at
  * given poses (s_binaryDumpSensorUseTrajectory = true, s_binaryDumpSensorUseTrajectoryOnlyInit = false), plus what is
  * not in the reference: how far the host may run ahead of the device, and where the frames live. */

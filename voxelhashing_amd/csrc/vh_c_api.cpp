@@ -44,10 +44,14 @@ int vh_scene_rep_integrate(VhSceneRep* s, const float rigidTransform[16], const 
     return guarded([&] { s->impl.integrate(toMat(rigidTransform), *cam, *cp, d_bitMask); });
 }
 int vh_scene_rep_integrate_ahead(VhSceneRep* s, const float rigidTransform[16], const VhDepthCameraData* cam,
-                                 const VhDepthCameraParams* cp, const uint32_t* d_bitMask)
+                                 const VhDepthCameraParams* cp, const uint32_t* d_bitMask, VhFrameJob** job)
 {
     if (!s || !rigidTransform || !cam || !cp) return VH_ERR_BAD_ARGUMENT;
-    return guarded([&] { s->impl.integrateAhead(toMat(rigidTransform), *cam, *cp, d_bitMask); });
+    if (job) *job = nullptr;
+    return guarded([&] {
+        VhFrameJob* j = s->impl.integrateAhead(toMat(rigidTransform), *cam, *cp, d_bitMask);
+        if (job) *job = j;
+    });
 }
 int vh_scene_rep_integrate_finish(VhSceneRep* s, const VhDepthCameraData* cam, const VhDepthCameraParams* cp)
 {
@@ -121,6 +125,12 @@ int vh_raycast_render(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp
 {
     if (!r || !hd || !hp || !cp || !lastRigidTransform) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { r->impl.render(*hd, *hp, *cp, toMat(lastRigidTransform)); });
+}
+int vh_raycast_render_co(VhRayCast* r, const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraParams* cp,
+                         const float lastRigidTransform[16], VhFrameJob* job)
+{
+    if (!r || !hd || !hp || !cp || !lastRigidTransform) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.render(*hd, *hp, *cp, toMat(lastRigidTransform), job); });
 }
 int vh_raycast_get_data(VhRayCast* r, VhRayCastData* out)
 {

@@ -281,16 +281,15 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
     m_occupiedPending = false;
     m_counterCleared = false;
     m_timer = new VhStageTimer(3);
-    m_sideStream = nullptr;
-    for (void*& e : m_aheadEvents) e = nullptr;
-    m_aheadSlot = 0;
     m_aheadPending = 0;
-    m_aheadBitMask = nullptr;
+    d_packedFrame = nullptr;
+    m_packedPixels = 0;
+    std::memset(&m_job, 0, sizeof(m_job));
     std::memset(&m_hashData, 0, sizeof(m_hashData));
     check(vh_hash_data_alloc(&m_hashData, &m_hashParams), "HashData::allocate");
     // mapped pinned word the fused integrate kernel mirrors the in-frustum block count into
-    checkHip(hipHostMalloc((void**)&h_occupied, sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc");
-    *h_occupied = 0;
+    checkHip(hipHostMalloc((void**)&h_occupied, 2 * sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc");
+    h_occupied[0] = h_occupied[1] = 0;
     void* dptr = nullptr;
     checkHip(hipHostGetDevicePointer(&dptr, h_occupied, 0), "hipHostGetDevicePointer");
     m_occupiedEvent = dptr; // device alias of h_occupied
@@ -299,13 +298,10 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
 
 void CUDASceneRepHashSDF::destroy()
 {
-    if (m_sideStream) (void)hipStreamSynchronize((hipStream_t)m_sideStream);
     (void)hipStreamSynchronize((hipStream_t)m_stream);
     delete m_timer;
     m_timer = nullptr;
-    for (void*& e : m_aheadEvents)
-        if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
-    if (m_sideStream) { (void)hipStreamDestroy((hipStream_t)m_sideStream); m_sideStream = nullptr; }
+    if (d_packedFrame) { (void)hipFree(d_packedFrame); d_packedFrame = nullptr; }
     if (h_occupied) (void)hipHostFree(h_occupied);
     vh_hash_data_free(&m_hashData);
 }
@@ -317,10 +313,10 @@ void CUDASceneRepHashSDF::reset()
     const vh::mat4f id = vh::mat4f::identity();
     std::memcpy(m_hashParams.m_rigidTransform, id.m, sizeof(id.m));
     std::memcpy(m_hashParams.m_rigidTransformInverse, id.m, sizeof(id.m));
-    if (m_sideStream) checkHip(hipStreamSynchronize((hipStream_t)m_sideStream), "hipStreamSynchronize");
     m_aheadPending = 0;
+    m_occupiedPending = true; // reset() waits for the device before it clears the mapped words
     pollOccupiedCount(true);
-    *h_occupied = 0;
+    h_occupied[0] = h_occupied[1] = 0;
     m_hashParams.m_numOccupiedBlocks = 0;
     m_counterCleared = false;
     m_lockEpoch = 0;
@@ -349,7 +345,7 @@ void CUDASceneRepHashSDF::setLastRigidTransform(const vh::mat4f& t)
 void CUDASceneRepHashSDF::setLastRigidTransformAndCompactify(const vh::mat4f& t, const DepthCameraParams& cp)
 {
     setLastRigidTransform(t);
-    compactifyHashEntries(cp, m_stream);
+    compactifyHashEntries(cp);
 }
 
 const vh::mat4f CUDASceneRepHashSDF::getLastRigidTransform() const
@@ -368,7 +364,7 @@ void CUDASceneRepHashSDF::pollOccupiedCount(bool block)
     }
     // the fused integrate kernel stores the count of its frame into the mapped word; without blocking this is
     // the count of the most recent frame whose kernel has run
-    m_hashParams.m_numOccupiedBlocks = *(volatile uint32_t*)h_occupied;
+    m_hashParams.m_numOccupiedBlocks = ((volatile uint32_t*)h_occupied)[0];
 }
 
 const HashParams& CUDASceneRepHashSDF::getHashParams()
@@ -395,14 +391,39 @@ unsigned int CUDASceneRepHashSDF::getHeapFreeCount()
     return count + 1;
 }
 
+unsigned int CUDASceneRepHashSDF::getNumFramesStartedOnDevice() const { return ((volatile uint32_t*)h_occupied)[1]; }
+
+// the alloc + compactify passes of the frame whose pose has just been set, as a job
+void CUDASceneRepHashSDF::prepareJob(const DepthCameraData& cam, const DepthCameraParams& cp, const unsigned int* d_bitMask)
+{
+    const size_t pixels = (size_t)cp.m_imageWidth * cp.m_imageHeight;
+    if (pixels > m_packedPixels) { // the packed frame follows the image size (first frame, or a larger adapter image)
+        if (d_packedFrame) {
+            checkHip(hipStreamSynchronize((hipStream_t)m_stream), "hipStreamSynchronize");
+            checkHip(hipFree(d_packedFrame), "hipFree");
+            d_packedFrame = nullptr;
+        }
+        checkHip(hipMalloc(&d_packedFrame, 8 * pixels), "packed frame");
+        m_packedPixels = pixels;
+    }
+    std::memset(&m_job, 0, sizeof(m_job));
+    m_job.hashData = m_hashData;
+    m_job.hashParams = m_hashParams;
+    m_job.cam = cam;
+    m_job.cp = cp;
+    m_job.d_bitMask = d_bitMask;
+    m_job.d_packedFrame = d_packedFrame;
+    m_job.lockToken = nextLockToken();
+}
+
 // DSC/CUDASceneRepHashSDF.h:64-83
 void CUDASceneRepHashSDF::integrate(const vh::mat4f& lastRigidTransform, const DepthCameraData& cam,
                                     const DepthCameraParams& cp, const unsigned int* d_bitMask)
 {
     if (m_aheadPending) throw vh::Error(VH_ERR_BAD_ARGUMENT, "integrate(): integrateAhead() is waiting for its integrateFinish()");
     setLastRigidTransform(lastRigidTransform);
-    alloc(cam, cp, d_bitMask, m_stream);
-    compactifyHashEntries(cp, m_stream);
+    alloc(cam, cp, d_bitMask, false);
+    compactifyHashEntries(cp);
     if (m_options.s_useReferenceLaunchSequence) {
         integrateDepthMap(cam, cp);
         garbageCollect(cp);
@@ -424,83 +445,74 @@ void CUDASceneRepHashSDF::integrateFused(const DepthCameraData& cam, const Depth
     }
     const bool timed = m_options.s_timingsDetailledEnabled;
     if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
-    check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), (uint32_t*)m_occupiedEvent, m_stream), "integrate (fused)");
+    // the packed frame is this frame's only if this frame's alloc pass wrote it (same image, same size)
+    const bool packedIsCurrent = m_job.allocLaunched && m_job.d_packedFrame && m_job.cam.d_depthData == cam.d_depthData &&
+                                 m_job.cam.d_colorData == cam.d_colorData && m_job.cp.m_imageWidth == cp.m_imageWidth &&
+                                 m_job.cp.m_imageHeight == cp.m_imageHeight;
+    check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), (uint32_t*)m_occupiedEvent,
+                             m_numIntegratedFrames + 1u, packedIsCurrent ? m_job.d_packedFrame : nullptr, m_stream), "integrate (fused)");
     m_occupiedPending = true;
     if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
 }
 
-// first half of integrate() on the side stream (see include/vh.hpp)
-void CUDASceneRepHashSDF::integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& cam,
-                                         const DepthCameraParams& cp, const unsigned int* d_bitMask)
+// first half of integrate(): the pose, and alloc + compactify as a job for a co-launch (see include/vh.hpp)
+VhFrameJob* CUDASceneRepHashSDF::integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& cam,
+                                                const DepthCameraParams& cp, const unsigned int* d_bitMask)
 {
     if (m_aheadPending) throw vh::Error(VH_ERR_BAD_ARGUMENT, "integrateAhead(): the previous one has not been finished");
-    if (m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence) {
-        m_aheadTransform = lastRigidTransform;
-        m_aheadBitMask = d_bitMask;
-        m_aheadPending = 2;
-        return;
-    }
-    if (!m_sideStream) {
-        hipStream_t s = nullptr;
-        checkHip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-        m_sideStream = (vhStream_t)s;
-        for (void*& e : m_aheadEvents) {
-            hipEvent_t ev = nullptr;
-            checkHip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
-            e = (void*)ev;
-        }
-    }
     setLastRigidTransform(lastRigidTransform);
-    m_aheadSlot = (m_aheadSlot + 2u) % 8u;
-    hipEvent_t toSide = (hipEvent_t)m_aheadEvents[m_aheadSlot], toMain = (hipEvent_t)m_aheadEvents[m_aheadSlot + 1u];
-    // behind everything the main stream holds now: the previous frame's pass over the voxels (its garbage collection
-    // edits the table) and whatever produced this frame's depth map
-    checkHip(hipEventRecord(toSide, (hipStream_t)m_stream), "hipEventRecord");
-    checkHip(hipStreamWaitEvent((hipStream_t)m_sideStream, toSide, 0), "hipStreamWaitEvent");
-    alloc(cam, cp, d_bitMask, m_sideStream);
-    compactifyHashEntries(cp, m_sideStream);
-    checkHip(hipEventRecord(toMain, (hipStream_t)m_sideStream), "hipEventRecord");
+    prepareJob(cam, cp, d_bitMask);
     m_aheadPending = 1;
+    // offline mode loops over alloc with read-backs, the reference sequence reads the compactify count: not for a co-launch
+    if (m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence || m_options.s_timingsDetailledEnabled) return nullptr;
+    return &m_job;
 }
 
 void CUDASceneRepHashSDF::integrateFinish(const DepthCameraData& cam, const DepthCameraParams& cp)
 {
     if (!m_aheadPending) throw vh::Error(VH_ERR_BAD_ARGUMENT, "integrateFinish() without integrateAhead()");
-    if (m_aheadPending == 2) {
-        m_aheadPending = 0;
-        integrate(m_aheadTransform, cam, cp, m_aheadBitMask);
-        return;
-    }
     m_aheadPending = 0;
-    checkHip(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_aheadEvents[m_aheadSlot + 1u], 0), "hipStreamWaitEvent");
-    integrateFused(cam, cp);
+    if (m_job.allocLaunched) m_counterCleared = true;
+    else alloc(cam, cp, m_job.d_bitMask, true);
+    if (m_job.compactifyLaunched) m_counterCleared = false;
+    else compactifyHashEntries(cp);
+    if (m_options.s_useReferenceLaunchSequence) {
+        integrateDepthMap(cam, cp);
+        garbageCollect(cp);
+    } else {
+        integrateFused(cam, cp);
+    }
     m_numIntegratedFrames++;
 }
 
 // DSC/CUDASceneRepHashSDF.h:247-279
-void CUDASceneRepHashSDF::alloc(const DepthCameraData& cam, const DepthCameraParams& cp, const unsigned int* d_bitMask, vhStream_t stream)
+void CUDASceneRepHashSDF::alloc(const DepthCameraData& cam, const DepthCameraParams& cp, const unsigned int* d_bitMask, bool jobPrepared)
 {
     const bool timed = m_options.s_timingsDetailledEnabled;
-    if (timed) m_timer->start(ST_ALLOC, (hipStream_t)stream);
+    if (timed) m_timer->start(ST_ALLOC, (hipStream_t)m_stream);
+    if (!jobPrepared) prepareJob(cam, cp, d_bitMask);
     if (m_options.s_offlineProcessing) {
         // allocate until all blocks are allocated (one blocking read-back per pass, as the reference)
         unsigned int prevFree = getHeapFreeCount();
         while (true) {
-            check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), stream), "allocCUDA");
+            m_job.allocLaunched = 0;
+            check(vh_alloc_job(&m_job, m_stream), "allocCUDA");
             unsigned int currFree = getHeapFreeCount();
             if (prevFree != currFree) prevFree = currFree;
             else break;
+            m_job.lockToken = nextLockToken();
         }
     } else {
-        check(vh_alloc(&m_hashData, &m_hashParams, &cam, &cp, d_bitMask, nextLockToken(), stream), "allocCUDA");
+        check(vh_alloc_job(&m_job, m_stream), "allocCUDA");
     }
     m_counterCleared = true; // k_alloc clears d_hashCompactifiedCounter
-    if (timed) m_timer->stop(ST_ALLOC, (hipStream_t)stream);
+    if (timed) m_timer->stop(ST_ALLOC, (hipStream_t)m_stream);
 }
 
 // DSC/CUDASceneRepHashSDF.h:282-315
-void CUDASceneRepHashSDF::compactifyHashEntries(const DepthCameraParams& cp, vhStream_t stream)
+void CUDASceneRepHashSDF::compactifyHashEntries(const DepthCameraParams& cp)
 {
+    vhStream_t stream = m_stream;
     const bool timed = m_options.s_timingsDetailledEnabled;
     if (timed) m_timer->start(ST_COMPACTIFY, (hipStream_t)stream);
     const bool needHostCount = m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence;
@@ -548,7 +560,6 @@ void CUDASceneRepHashSDF::getState(uint32_t out[VH_STATE_WORDS])
 
 void CUDASceneRepHashSDF::getTimings(double out[4])
 {
-    if (m_sideStream) checkHip(hipStreamSynchronize((hipStream_t)m_sideStream), "hipStreamSynchronize");
     m_timer->resolve((hipStream_t)m_stream);
     out[0] = m_timer->totalMs[ST_ALLOC];
     out[1] = m_timer->totalMs[ST_COMPACTIFY];
@@ -692,7 +703,7 @@ void CUDARayCastSDF::getTimings(double out[4])
 
 // DSC/CUDARayCastSDF.cpp:38-72 with rayIntervalSplatting :84-100 (view matrices only)
 void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashParams, const DepthCameraParams& cp,
-                            const vh::mat4f& lastRigidTransform)
+                            const vh::mat4f& lastRigidTransform, VhFrameJob* coLaunch)
 {
     m_params.m_numOccupiedSDFBlocks = hashParams.m_numOccupiedBlocks;
     const vh::mat4f view = lastRigidTransform.getInverse();
@@ -726,14 +737,14 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     if (!m_params.m_useGradients) out.d_normals = nullptr;
 #endif
     if (m_useIntervals) {
-        check(vh_render_intervals(&hashData, &hashParams, &out, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, m_stream), "renderCS");
+        check(vh_render_intervals_co(&hashData, &hashParams, &out, &cp, &m_params, d_tileHeads, d_tileBlocks, m_tileCapacity, d_schedule, m_phase, coLaunch, m_stream), "renderCS");
     } else {
         check(vh_render(&hashData, &hashParams, &out, &cp, &m_params, m_stream), "renderCS");
     }
     if (timed) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {
         if (timedAll) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
-        check(vh_compute_normals(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, m_stream), "computeNormals");
+        check(vh_compute_normals_co(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, coLaunch, m_stream), "computeNormals");
         if (timedAll) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
     }
 }

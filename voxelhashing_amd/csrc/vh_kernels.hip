@@ -11,6 +11,8 @@
 // MUST be compiled with -ffp-contract=off (see vh_device.hpp).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "../../include/vh_api.h"
 #include "vh_device.hpp"
 #include "vh_host_util.hpp"
@@ -76,24 +78,42 @@ VHD bool block_streamed_out(const VhHashParams& hp, I3 blk, const uint32_t* bitM
     return (bitMask[index >> 5] & (1u << (index & 31))) != 0u;
 }
 
-__global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
-                                               VhDepthCameraParams cp, const uint32_t* bitMask, int32_t lockToken, HashMod hm)
+// What integrateDepthMapKernel reads of a pixel (DSC/CUDASceneRepHashSDF.cu:436-470), formed once per pixel instead
+// of once per voxel that projects onto it: the depth, the colour as the bytes the kernel would make of it
+// (uchar(255 * c), :466) and the weight of the sample (:463-464, a function of the depth alone).  Weight 0 marks a
+// pixel that integrates nothing: invalid depth or colour, or beyond the integration distance (:443-445); a valid
+// sample weighs at least 1.
+VHD uint2 pack_pixel(const VhHashParams& hp, const VhDepthCameraParams& cp, float depth, bool hasColor, float4 c)
+{
+    uint32_t cw = 0u;
+    if (hasColor && c.x != minf() && depth != minf() && depth < hp.m_maxIntegrationDistance) {
+        const float depthZeroOne = cam_to_proj_z(cp, depth);
+        const float weightUpdate = fmaxf((float)hp.m_integrationWeightSample * 1.5f * (1.0f - depthZeroOne), 1.0f);
+        cw = pack_cw(f2uc(255.0f * c.x), f2uc(255.0f * c.y), f2uc(255.0f * c.z), f2uc(weightUpdate));
+    }
+    return make_uint2(__float_as_uint(depth), cw);
+}
+
+// one wave, one 8x8 pixel tile
+VHD void alloc_tile(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraData& cam, const VhDepthCameraParams& cp,
+                    const uint32_t* bitMask, int32_t lockToken, HashMod hm, uint2* packed, uint32_t tile)
 {
     const uint32_t lane = lane_id();
     const uint32_t W = cp.m_imageWidth, H = cp.m_imageHeight;
     const uint32_t tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
-    const uint32_t tile = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    // the compaction that follows needs its counter at zero: cleared here instead of by a separate memset
-    if (blockIdx.x == 0 && threadIdx.x == 0) hd.d_hashCompactifiedCounter[0] = 0;
     if (tile >= tilesX * tilesY) return; // wave-uniform
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
     const float vs = hp.m_virtualVoxelSize;
 
     bool active = (x < W) && (y < H);
     float d = active ? cam.d_depthData[y * W + x] : minf();
+    if (packed && active) { // the frame as the integrate pass reads it (a 128-byte row segment per 8 lanes)
+        float4 c = make_float4(minf(), minf(), minf(), minf());
+        if (cam.d_colorData) c = reinterpret_cast<const float4*>(cam.d_colorData)[y * W + x];
+        packed[y * W + x] = pack_pixel(hp, cp, d, cam.d_colorData != nullptr, c);
+    }
     if (d == minf() || d == 0.0f) active = false;
     if (d >= hp.m_maxIntegrationDistance) active = false;
-
     const float t = get_truncation(hp, d);
     const float minDepth = fminf(hp.m_maxIntegrationDistance, d - t);
     const float maxDepth = fminf(hp.m_maxIntegrationDistance, d + t);
@@ -172,6 +192,14 @@ __global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, V
     }
 }
 
+__global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, VhDepthCameraData cam,
+                                               VhDepthCameraParams cp, const uint32_t* bitMask, int32_t lockToken, HashMod hm, uint2* packed)
+{
+    // the compaction that follows needs its counter at zero: cleared here instead of by a separate memset
+    if (blockIdx.x == 0 && threadIdx.x == 0) hd.d_hashCompactifiedCounter[0] = 0;
+    alloc_tile(hd, hp, cam, cp, bitMask, lockToken, hm, packed, blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+}
+
 // ---------------------------------------------------------------------------
 // compactify (compactifyHashAllInOneKernel, DSC/CUDASceneRepHashSDF.cu:317-359)
 //
@@ -181,10 +209,10 @@ __global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, V
 // prefix and ONE atomic per wave.
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp)
+// one lane per word of 32 occupancy bits (whole waves take part: ballots inside)
+VHD void compactify_words(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, uint32_t wordIdx)
 {
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
-    const uint32_t wordIdx = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bits = (wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
     while (__any(bits != 0u)) {
         const bool has = bits != 0u;
@@ -220,6 +248,11 @@ __global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams 
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp)
+{
+    compactify_words(hd, hp, cp, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -351,6 +384,109 @@ __global__ __launch_bounds__(256) void k_integrate(VhHashData hd, VhHashParams h
             const uint2 a = pack_vox(v0), c = pack_vox(v1);
             *vp = make_uint4(a.x, a.y, c.x, c.y);
         }
+    }
+}
+
+// integrate_voxel on a frame packed by alloc_tile / pack_pixel: one 8-byte gather per voxel
+VHD Vox integrate_voxel_packed(const VhHashParams& hp, const VhDepthCameraParams& cp, const uint2* packed, I3 pi, Vox stored)
+{
+    F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pi));
+    const uint32_t sx = (uint32_t)f2i((pf.x * cp.fx / pf.z + cp.mx) + 0.5f);
+    const uint32_t sy = (uint32_t)f2i((pf.y * cp.fy / pf.z + cp.my) + 0.5f);
+    if (sx < cp.m_imageWidth && sy < cp.m_imageHeight) {
+        const uint2 px = packed[sy * cp.m_imageWidth + sx];
+        if ((px.y >> 24) != 0u) { // a sample: valid depth within the integration distance, valid colour
+            const float depth = __uint_as_float(px.x);
+            float sdf = depth - pf.z;
+            const float truncation = get_truncation(hp, depth);
+            if (sdf > -truncation) {
+                if (sdf >= 0.0f) sdf = fminf(truncation, sdf);
+                else sdf = fmaxf(-truncation, sdf);
+                Vox curr;
+                curr.sdf = sdf;
+                curr.cw = px.y;
+                return combine_voxel(hp, stored, curr);
+            }
+        }
+    }
+    return stored;
+}
+
+// The fused pass, one WAVE per SDF block: a block is 4 KB, four 16-byte loads per lane, all in flight before the first
+// is used (load j of lane l holds voxels 128 j + 2 l and + 1: x = 2l mod 8 (+1), y = (l / 4) mod 8, z = 2j + l / 32);
+// min |sdf| / max weight of the block are a wave reduction (no LDS, no barrier), lane 0 edits the table for a block
+// that garbage collection frees.  The grid is persistent (the block count lives on the device); wave w of workgroup g
+// takes blocks w * gridDim + g, + 4 gridDim, ...: a frame with few blocks spreads them over all compute units.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, VhDepthCameraParams cp,
+                                                         uint32_t flags, int32_t lockToken, uint32_t* countMirror, uint32_t mirrorTag,
+                                                         const uint2* packed)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t nWaves = gridDim.x * (blockDim.x / kWave);
+    uint32_t b = wave * gridDim.x + blockIdx.x;
+    // the count and this wave's first entry in one trip (the list is Ne entries long: reading beyond the count is
+    // reading stale entries, which are not used)
+    const uint32_t count = (uint32_t)hd.d_hashCompactifiedCounter[0];
+    int4 q = make_int4(0, 0, 0, 0);
+    if (b < hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) q = load_quad(&hd.d_hashCompactified[b]);
+    // host-visible copy of the block count and the caller's tag (mapped pinned memory): replaces a per-frame
+    // device->host copy, and lets the host see how far the device has come
+    if (countMirror && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint2*>(countMirror) = make_uint2(count, mirrorTag);
+    const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
+    const float thr = get_truncation(hp, cp.m_sensorDepthWorldMax);
+
+    while (b < count) {
+        const int ex = __builtin_amdgcn_readfirstlane(q.x), ey = __builtin_amdgcn_readfirstlane(q.y);
+        const int ez = __builtin_amdgcn_readfirstlane(q.z), ptr = __builtin_amdgcn_readfirstlane(q.w);
+        uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + lane;
+        uint4 raw[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[j] = vp[j * kWave];
+        const uint32_t bNext = b + nWaves;
+        if (bNext < count) q = load_quad(&hd.d_hashCompactified[bNext]); // the next block's entry behind this block's voxels
+
+        float minSdf = pinf();
+        uint32_t maxW = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            Vox v0 = unpack_vox(make_uint2(raw[j].x, raw[j].y)), v1 = unpack_vox(make_uint2(raw[j].z, raw[j].w));
+            const I3 p0 = mki3(ex * VH_SDF_BLOCK_SIZE + lx, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0);
+            if (PACKED) {
+                v0 = integrate_voxel_packed(hp, cp, packed, p0, v0);
+                v1 = integrate_voxel_packed(hp, cp, packed, mki3(p0.x + 1, p0.y, p0.z), v1);
+            } else {
+                v0 = integrate_voxel(hp, cp, cam, p0, v0);
+                v1 = integrate_voxel(hp, cp, cam, mki3(p0.x + 1, p0.y, p0.z), v1);
+            }
+            // Pin the result words in VGPRs here (see k_integrate: hipcc merged the "not integrated" path of a voxel with a
+            // register the gather had already overwritten).
+            asm volatile("" : "+v"(v0.sdf), "+v"(v0.cw), "+v"(v1.sdf), "+v"(v1.cw));
+            if (flags & VH_FUSED_STARVE) { v0 = starve_voxel(v0); v1 = starve_voxel(v1); }
+            minSdf = fminf(minSdf, fminf(gc_key(v0), gc_key(v1)));
+            maxW = max(maxW, max(v0.weight(), v1.weight()));
+            const uint2 a = pack_vox(v0), c = pack_vox(v1);
+            raw[j] = make_uint4(a.x, a.y, c.x, c.y);
+        }
+        bool freed = false;
+        if (flags & VH_FUSED_GC) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                minSdf = fminf(minSdf, __shfl_xor(minSdf, o));
+                maxW = max(maxW, (uint32_t)__shfl_xor((int)maxW, o));
+            }
+            const bool decide = (minSdf >= thr) || (maxW == 0u);
+            int f = 0;
+            if (lane == 0) {
+                hd.d_hashDecision[b] = decide ? 1 : 0;
+                f = (decide && delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), lockToken)) ? 1 : 0;
+            }
+            freed = __builtin_amdgcn_readfirstlane(f) != 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) vp[j * kWave] = freed ? make_uint4(0u, 0u, 0u, 0u) : raw[j];
+        b = bNext;
     }
 }
 
@@ -1389,12 +1525,42 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
 
 // small tables: 5 waves per SIMD keep all tiles of a 640x480 frame resident at once (4800 waves <= 5 x 4 x 256): the
 // march is a latency chain, and a second round of waves costs as much as the first
+// Co-launch (CUDASceneRepHashSDF::integrateAhead): the workgroups behind the ray caster's own, `firstGroup` onwards,
+// run the alloc pass of the NEXT frame (four 8x8 pixel tiles each), and the workgroups behind computeNormals' own run
+// its compactify pass.  One launch instead of two streams: the extra workgroups are dispatched as the ray caster's
+// waves retire, so they fill the tail its few dearest tiles leave, and no event or second queue is involved.  A block
+// allocated while rays are marched holds only unobserved voxels (weight 0), which a sample treats exactly like an
+// absent block, and the ray caster reads the table through k_interval_splat's lists, made before this launch.
+struct CoAlloc {
+    VhHashData hd;
+    VhHashParams hp; // of the frame being allocated (its pose)
+    VhDepthCameraData cam;
+    VhDepthCameraParams cp;
+    const uint32_t* bitMask;
+    uint2* packed;
+    HashMod hm;
+    int32_t lockToken;
+    uint32_t firstGroup; // 0: nothing to co-launch
+};
+
+VHD bool co_alloc(const CoAlloc& job)
+{
+    if (job.firstGroup == 0u || blockIdx.x < job.firstGroup) return false;
+    const uint32_t g = blockIdx.x - job.firstGroup;
+    if (g == 0u && threadIdx.x == 0) job.hd.d_hashCompactifiedCounter[0] = 0; // as k_alloc
+    alloc_tile(job.hd, job.hp, job.cam, job.cp, job.bitMask, job.lockToken, job.hm, job.packed, g * (256u / kWave) + (threadIdx.x / kWave));
+    return true;
+}
+
+// small tables: 5 waves per SIMD keep all tiles of a 640x480 frame resident at once (4800 waves <= 5 x 4 x 256): the
+// march is a latency chain, and a second round of waves costs as much as the first
 template <bool GRADIENTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
-              uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase)
+              uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase, CoAlloc job)
 {
     __shared__ int tileTab[256 / kWave][2u * VH_TILE_LIST_CAPACITY * kTileSlotWords];
+    if (co_alloc(job)) return;
     render_tile<GRADIENTS, VH_TILE_LIST_CAPACITY>(hd, hp, rd, cp, rp, heads, lists, cap, sched, phase, tileTab);
 }
 
@@ -1402,15 +1568,27 @@ void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraPar
 template <bool GRADIENTS>
 __global__ __launch_bounds__(256)
 void k_render_large(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
-                    uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase)
+                    uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase, CoAlloc job)
 {
     __shared__ int tileTab[256 / kWave][2u * VH_TILE_LIST_CAPACITY_LARGE * kTileSlotWords];
+    if (co_alloc(job)) return;
     render_tile<GRADIENTS, VH_TILE_LIST_CAPACITY_LARGE>(hd, hp, rd, cp, rp, heads, lists, cap, sched, phase, tileTab);
 }
 
+struct CoCompactify {
+    VhHashData hd;
+    VhHashParams hp;
+    VhDepthCameraParams cp;
+    uint32_t firstGroup; // 0: nothing to co-launch
+};
+
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
-__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height)
+__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job)
 {
+    if (job.firstGroup != 0u && blockIdx.x >= job.firstGroup) {
+        compactify_words(job.hd, job.hp, job.cp, (blockIdx.x - job.firstGroup) * blockDim.x + threadIdx.x);
+        return;
+    }
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= width * height) return;
     const uint32_t x = idx % width, y = idx / width;
@@ -1730,6 +1908,37 @@ __global__ __launch_bounds__(256) void k_convert_color_raw_to_float4(float4* out
     const float mi = minf();
     out[i] = (r == 0u && g == 0u && b == 0u) ? make_float4(mi, mi, mi, mi)
                                              : make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)(w / 255u));
+}
+
+// A sensor frame straight from (pinned, device-visible) host memory: the depth copied, the colour converted on the way
+// (convertColorRawToFloatDevice above) -- one pass over the PCIe link, four pixels per lane (16-byte reads), no staging
+// copy of the raw colour.  Takes the place of the two uploads + the conversion of CUDARGBDAdapter::process
+// (DSC/CUDARGBDAdapter.cpp:107-131) for a frame at adapter resolution.
+__global__ __launch_bounds__(256) void k_upload_frame(const uint4* hostDepth, const uint4* hostRGBX, uint4* depth, float4* color, uint32_t nQuads, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nQuads) return;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 dn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&hostDepth[i]));
+    const uint4 d = make_uint4(dn.x, dn.y, dn.z, dn.w);
+    if (4u * i + 3u < n) depth[i] = d;
+    else {
+        const uint32_t dv[4] = { d.x, d.y, d.z, d.w };
+        for (uint32_t k = 0; 4u * i + k < n; k++) reinterpret_cast<uint32_t*>(depth)[4u * i + k] = dv[k];
+    }
+    if (!hostRGBX) return;
+    const u32x4 cn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&hostRGBX[i]));
+    const uint4 c4 = make_uint4(cn.x, cn.y, cn.z, cn.w);
+    const uint32_t cv[4] = { c4.x, c4.y, c4.z, c4.w };
+    const float mi = minf();
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        if (4u * i + k >= n) break;
+        const uint32_t c = cv[k];
+        const uint32_t r = c & 0xffu, g = (c >> 8) & 0xffu, b = (c >> 16) & 0xffu, w = c >> 24;
+        color[4u * i + k] = (r == 0u && g == 0u && b == 0u) ? make_float4(mi, mi, mi, mi)
+                                                            : make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)(w / 255u));
+    }
 }
 
 // bilinearInterpolationFloat :1071-1098 (invalid taps drop out of the weights)
@@ -2435,7 +2644,28 @@ int vh_alloc(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraDa
     const uint32_t tiles = cdiv(cp->m_imageWidth, 8) * cdiv(cp->m_imageHeight, 8);
     if (tiles == 0) return VH_OK;
     if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
-    k_alloc<<<cdiv(tiles, 8), 512, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken, make_hash_mod(hp->m_hashNumBuckets));
+    k_alloc<<<cdiv(tiles, 8), 512, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, d_bitMask, lockToken, make_hash_mod(hp->m_hashNumBuckets), nullptr);
+    return vh_last_launch_error();
+}
+
+int vh_alloc_job(VhFrameJob* job, vhStream_t stream)
+{
+    if (!job || !job->cam.d_depthData || !job->hashData.d_hash) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t tiles = cdiv(job->cp.m_imageWidth, 8) * cdiv(job->cp.m_imageHeight, 8);
+    if (job->hashParams.m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
+    job->allocLaunched = 1;
+    if (tiles == 0) return VH_OK;
+    k_alloc<<<cdiv(tiles, 8), 512, 0, (hipStream_t)stream>>>(job->hashData, job->hashParams, job->cam, job->cp, job->d_bitMask, job->lockToken,
+                                                             make_hash_mod(job->hashParams.m_hashNumBuckets), reinterpret_cast<uint2*>(job->d_packedFrame));
+    return vh_last_launch_error();
+}
+
+int vh_compactify_job(VhFrameJob* job, vhStream_t stream)
+{
+    if (!job || !job->hashData.d_hash) return VH_ERR_BAD_ARGUMENT;
+    job->compactifyLaunched = 1;
+    const uint32_t nWords = (job->hashParams.m_hashNumBuckets + 31) / 32;
+    k_compactify<<<cdiv(nWords, 256), 256, 0, (hipStream_t)stream>>>(job->hashData, job->hashParams, job->cp);
     return vh_last_launch_error();
 }
 
@@ -2465,13 +2695,20 @@ int vh_integrate(const VhHashData* hd, const VhHashParams* hp, const VhDepthCame
     return vh_last_launch_error();
 }
 
+static uint32_t device_num_cus();
+
 int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDepthCameraData* cam,
-                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, uint32_t* d_countMirror, vhStream_t stream)
+                       const VhDepthCameraParams* cp, uint32_t flags, int32_t lockToken, uint32_t* d_countMirror, uint32_t mirrorTag,
+                       const void* d_packedFrame, vhStream_t stream)
 {
     if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
-    // persistent grid: the block count lives on the device, so no host read-back is needed
-    const uint32_t grid = hp->m_numSDFBlocks < 2048u ? hp->m_numSDFBlocks : 2048u;
-    k_integrate<true><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken, d_countMirror);
+    // persistent grid: the block count lives on the device, so no host read-back is needed.  One wave per block, four
+    // per workgroup, up to eight workgroups per compute unit.
+    const uint32_t want = cdiv(hp->m_numSDFBlocks, 4), most = device_num_cus() * 8u;
+    const uint32_t grid = want < most ? want : most;
+    const uint2* packed = reinterpret_cast<const uint2*>(d_packedFrame);
+    if (packed) k_integrate_fused<true><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken, d_countMirror, mirrorTag, packed);
+    else k_integrate_fused<false><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken, d_countMirror, mirrorTag, nullptr);
     return vh_last_launch_error();
 }
 
@@ -2538,9 +2775,9 @@ size_t vh_render_schedule_bytes(uint32_t width, uint32_t height)
 
 uint32_t vh_render_split_tiles(uint32_t width, uint32_t height) { return split_tiles(cdiv(width, 8) * cdiv(height, 8)); }
 
-int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
-                        const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
-                        uint32_t* d_schedule, uint32_t phase, vhStream_t stream)
+int vh_render_intervals_co(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
+                           const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                           uint32_t* d_schedule, uint32_t phase, VhFrameJob* fj, vhStream_t stream)
 {
     if (!hd || !hp || !rd || !cp || !rp || !rd->d_depth || !d_tileHeads) return VH_ERR_BAD_ARGUMENT;
     const uint32_t tiles = cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8);
@@ -2550,16 +2787,37 @@ int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRa
     const uint32_t cap = d_tileBlocks ? tileCapacity : 0u;
     // the capacity of the lists picks the table size: up to VH_TILE_LIST_CAPACITY the small tables, beyond it the large ones
     const bool large = cap > (uint32_t)VH_TILE_LIST_CAPACITY;
-    const dim3 grid(cdiv(tiles + (d_schedule ? split_tiles(tiles) : 0u), 4));
+    uint32_t groups = cdiv(tiles + (d_schedule ? split_tiles(tiles) : 0u), 4);
+    CoAlloc job;
+    std::memset(&job, 0, sizeof(job));
+    if (fj && !fj->allocLaunched && fj->cam.d_depthData && fj->hashData.d_hash && fj->hashParams.m_hashNumBuckets >= 2) {
+        const uint32_t allocTiles = cdiv(fj->cp.m_imageWidth, 8) * cdiv(fj->cp.m_imageHeight, 8);
+        job.hd = fj->hashData; job.hp = fj->hashParams; job.cam = fj->cam; job.cp = fj->cp;
+        job.bitMask = fj->d_bitMask;
+        job.packed = reinterpret_cast<uint2*>(fj->d_packedFrame);
+        job.hm = make_hash_mod(fj->hashParams.m_hashNumBuckets);
+        job.lockToken = fj->lockToken;
+        job.firstGroup = groups;
+        groups += cdiv(allocTiles, 4);
+        fj->allocLaunched = 1;
+    }
+    const dim3 grid(groups);
     hipStream_t st = (hipStream_t)stream;
     if (rp->m_useGradients) {
-        if (large) k_render_large<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
-        else k_render<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+        if (large) k_render_large<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
+        else k_render<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
     } else {
-        if (large) k_render_large<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
-        else k_render<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase);
+        if (large) k_render_large<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
+        else k_render<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
     }
     return vh_last_launch_error();
+}
+
+int vh_render_intervals(const VhHashData* hd, const VhHashParams* hp, const VhRayCastData* rd, const VhDepthCameraParams* cp,
+                        const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                        uint32_t* d_schedule, uint32_t phase, vhStream_t stream)
+{
+    return vh_render_intervals_co(hd, hp, rd, cp, rp, d_tileHeads, d_tileBlocks, tileCapacity, d_schedule, phase, nullptr, stream);
 }
 
 int vh_ray_interval_clear(uint32_t* d_tileHeads, uint32_t width, uint32_t height, vhStream_t stream)
@@ -2586,13 +2844,26 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
     return vh_last_launch_error();
 }
 
-int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream)
+int vh_compute_normals_co(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* fj, vhStream_t stream)
 {
     if (!d_output4 || !d_input4) return VH_ERR_BAD_ARGUMENT;
     if (width * height == 0) return VH_OK;
-    k_compute_normals<<<cdiv((uint64_t)width * height, 256), 256, 0, (hipStream_t)stream>>>(
-        reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height);
+    uint32_t groups = cdiv((uint64_t)width * height, 256);
+    CoCompactify job;
+    std::memset(&job, 0, sizeof(job));
+    if (fj && fj->allocLaunched && !fj->compactifyLaunched && fj->hashData.d_hash) {
+        job.hd = fj->hashData; job.hp = fj->hashParams; job.cp = fj->cp;
+        job.firstGroup = groups;
+        groups += cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, 256);
+        fj->compactifyLaunched = 1;
+    }
+    k_compute_normals<<<groups, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job);
     return vh_last_launch_error();
+}
+
+int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    return vh_compute_normals_co(d_output4, d_input4, width, height, nullptr, stream);
 }
 
 int vh_reset_marching_cubes(const VhMarchingCubesData* data, vhStream_t stream)
@@ -2628,6 +2899,20 @@ int vh_convert_color_raw_to_float4(float* d_output4, const uint8_t* d_inputRGBX,
     k_convert_color_raw_to_float4<<<VH_IMG_LAUNCH(width * height)>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const uint32_t*>(d_inputRGBX), width * height);
     return vh_last_launch_error();
 }
+int vh_upload_frame(const float* hostDepth, const uint8_t* hostRGBX, float* d_depth, float* d_color4, uint32_t width, uint32_t height, vhStream_t stream)
+{
+    if (!hostDepth || !d_depth || (hostRGBX && !d_color4)) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t n = width * height;
+    if (n == 0) return VH_OK;
+    // whole 16-byte reads: the last one may reach up to 12 bytes beyond n pixels, so the images must be padded to a
+    // multiple of four pixels (640x480 and every even-by-even size is)
+    if (n % 4u) return VH_ERR_BAD_ARGUMENT;
+    const uint32_t nQuads = n / 4u;
+    k_upload_frame<<<cdiv(nQuads, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const uint4*>(hostDepth), reinterpret_cast<const uint4*>(hostRGBX),
+                                                                     reinterpret_cast<uint4*>(d_depth), reinterpret_cast<float4*>(d_color4), nQuads, n);
+    return vh_last_launch_error();
+}
+
 int vh_resample_float_map(float* d_output, uint32_t outputWidth, uint32_t outputHeight, const float* d_input, uint32_t inputWidth, uint32_t inputHeight, vhStream_t stream)
 {
     if (!d_output || !d_input || inputWidth == 0 || inputHeight == 0) return VH_ERR_BAD_ARGUMENT;

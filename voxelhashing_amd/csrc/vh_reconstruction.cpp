@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "vh_handles.hpp"
 #include "vh_host_util.hpp"
@@ -76,10 +77,6 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
         m_slotReady[i] = m_slotFree[i] = nullptr;
         m_slotUsed[i] = false;
     }
-    if (m_opt.s_maxFramesInFlight) {
-        m_frameDone.resize(m_opt.s_maxFramesInFlight, nullptr);
-        for (void*& e : m_frameDone) e = (void*)newEvent(false);
-    }
     if (m_opt.s_framesOnHost) {
         const size_t n = (size_t)cp.m_imageWidth * cp.m_imageHeight;
         hipStream_t cs = nullptr;
@@ -99,8 +96,6 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
 Reconstruction::~Reconstruction()
 {
     try { synchronize(); } catch (...) {}
-    for (void* e : m_frameDone)
-        if (e) (void)hipEventDestroy((hipEvent_t)e);
     for (auto& p : m_uploadTimers) { (void)hipEventDestroy((hipEvent_t)p.first); (void)hipEventDestroy((hipEvent_t)p.second); }
     for (void* e : m_timerPool) (void)hipEventDestroy((hipEvent_t)e);
     for (int i = 0; i < 2; i++) {
@@ -160,12 +155,24 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
     };
     void* t0 = timerEvent();
     void* t1 = timerEvent();
+    // Pinned (device-visible) frames are read by a kernel straight over the link, colour converted on the way; anything
+    // else goes through hipMemcpyAsync (staged by the runtime) and the conversion kernel of the sensor path.
+    void *devDepth = nullptr, *devColor = nullptr;
+    const bool mapped = (n % 4u) == 0u && hipHostGetDevicePointer(&devDepth, const_cast<float*>(f.depth), 0) == hipSuccess &&
+                        (!f.color || hipHostGetDevicePointer(&devColor, const_cast<void*>(f.color), 0) == hipSuccess);
+    if (!mapped) (void)hipGetLastError();
     checkHip(hipEventRecord((hipEvent_t)t0, cs), "hipEventRecord");
-    checkHip(hipMemcpyAsync(d_stageDepth[slot], f.depth, sizeof(float) * n, hipMemcpyHostToDevice, cs), "upload depth");
-    if (f.color) checkHip(hipMemcpyAsync(d_stageColorRaw[slot], f.color, 4 * n, hipMemcpyHostToDevice, cs), "upload colour");
+    if (mapped) {
+        check(vh_upload_frame((const float*)devDepth, (const uint8_t*)devColor, d_stageDepth[slot], d_stageColor[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "vh_upload_frame");
+    } else {
+        checkHip(hipMemcpyAsync(d_stageDepth[slot], f.depth, sizeof(float) * n, hipMemcpyHostToDevice, cs), "upload depth");
+        if (f.color) {
+            checkHip(hipMemcpyAsync(d_stageColorRaw[slot], f.color, 4 * n, hipMemcpyHostToDevice, cs), "upload colour");
+            check(vh_convert_color_raw_to_float4(d_stageColor[slot], d_stageColorRaw[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "convertColorRawToFloat4");
+        }
+    }
     checkHip(hipEventRecord((hipEvent_t)t1, cs), "hipEventRecord");
     m_uploadTimers.emplace_back(t0, t1);
-    if (f.color) check(vh_convert_color_raw_to_float4(d_stageColor[slot], d_stageColorRaw[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "convertColorRawToFloat4");
     checkHip(hipEventRecord((hipEvent_t)m_slotReady[slot], cs), "hipEventRecord");
     checkHip(hipStreamWaitEvent(ms, (hipEvent_t)m_slotReady[slot], 0), "hipStreamWaitEvent");
     m_slotUsed[slot] = true;
@@ -199,9 +206,10 @@ void Reconstruction::frame(const SequenceFrame& f)
     const bool ahead = m_opt.s_allocAhead && m_opt.s_integrationEnabled && !streaming;
     // :750-751 (the pose the scene holds is the previous frame's)
     const vh::mat4f renderTransform = m_sceneRep->getLastRigidTransform();
-    if (ahead) m_sceneRep->integrateAhead(transformation, cam, m_cp, nullptr);
+    VhFrameJob* job = nullptr;
+    if (ahead) job = m_sceneRep->integrateAhead(transformation, cam, m_cp, nullptr);
     if (m_frameNumber > 0 && m_opt.s_renderEnabled) // :750 "getFrameNumber() > 1" with frames counted from 1
-        m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform); // :763
+        m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform, job); // :763
 
     const unsigned int* d_bitMask = nullptr;
     if (streaming) { // :881-900
@@ -251,17 +259,20 @@ void Reconstruction::run(const SequenceFrame* frames, unsigned int n)
     const double t0 = now();
     double waited = 0.0;
     const double streamWait0 = m_stats.hostWaitSeconds;
-    const unsigned int ring = (unsigned int)m_frameDone.size();
+    // Run-ahead bound without an event (a record idles the queue for ~6 us on this machine): the pass over the voxels
+    // mirrors the scene's frame counter into mapped host memory when it starts.  Only that (fused) pass does so.
+    const VhSceneOptions& so = m_sceneRep->getOptions();
+    const bool bounded = m_opt.s_maxFramesInFlight && m_opt.s_integrationEnabled && !so.s_useReferenceLaunchSequence;
     for (unsigned int i = 0; i < n; i++) {
-        if (ring && m_frameNumber >= ring) { // the frame that used this event `ring` frames ago must be done
+        if (bounded && m_sceneRep->getNumIntegratedFrames() - m_sceneRep->getNumFramesStartedOnDevice() >= m_opt.s_maxFramesInFlight) {
             const double w0 = now();
-            checkHip(hipEventSynchronize((hipEvent_t)m_frameDone[m_frameNumber % ring]), "hipEventSynchronize");
+            while (m_sceneRep->getNumIntegratedFrames() - m_sceneRep->getNumFramesStartedOnDevice() >= m_opt.s_maxFramesInFlight) {
+                std::this_thread::yield();
+                if (now() - w0 > 30.0) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction::run: the device made no progress for 30 s");
+            }
             waited += now() - w0;
         }
-        const unsigned int number = m_frameNumber;
         frame(frames[i]);
-        if (ring && m_frameNumber != number)
-            checkHip(hipEventRecord((hipEvent_t)m_frameDone[number % ring], (hipStream_t)m_sceneRep->getStream()), "hipEventRecord");
     }
     const double total = now() - t0, streamWait = m_stats.hostWaitSeconds - streamWait0;
     m_stats.hostWaitSeconds += waited;

@@ -91,9 +91,12 @@ class CUDASceneRepHashSDF:
               "CUDASceneRepHashSDF::integrate")
 
     def integrateAhead(self, lastRigidTransform, depthCameraData, depthCameraParams, d_bitMask=None):
+        """-> the frame's alloc + compactify job (a pointer for CUDARayCastSDF.render(..., coLaunch=job)) or None"""
         data = depthCameraData.data if isinstance(depthCameraData, DepthFrame) else depthCameraData
-        check(self.L.vh_scene_rep_integrate_ahead(self.handle, f16(lastRigidTransform), C.byref(data), C.byref(depthCameraParams), d_bitMask),
-              "CUDASceneRepHashSDF::integrateAhead")
+        job = C.POINTER(T.FrameJob)()
+        check(self.L.vh_scene_rep_integrate_ahead(self.handle, f16(lastRigidTransform), C.byref(data), C.byref(depthCameraParams), d_bitMask,
+                                                  C.byref(job)), "CUDASceneRepHashSDF::integrateAhead")
+        return job if job else None
 
     def integrateFinish(self, depthCameraData, depthCameraParams):
         data = depthCameraData.data if isinstance(depthCameraData, DepthFrame) else depthCameraData
@@ -207,7 +210,11 @@ class CUDARayCastSDF:
         except Exception:
             pass
 
-    def render(self, hashData, hashParams, depthCameraParams, lastRigidTransform):
+    def render(self, hashData, hashParams, depthCameraParams, lastRigidTransform, coLaunch=None):
+        if coLaunch is not None:
+            check(self.L.vh_raycast_render_co(self.handle, C.byref(hashData), C.byref(hashParams), C.byref(depthCameraParams),
+                                              f16(lastRigidTransform), coLaunch), "CUDARayCastSDF::render")
+            return
         check(self.L.vh_raycast_render(self.handle, C.byref(hashData), C.byref(hashParams), C.byref(depthCameraParams),
                                        f16(lastRigidTransform)), "CUDARayCastSDF::render")
 
@@ -453,9 +460,27 @@ class LauncherScene:
     def integrate(self, frame, cp):
         check(self.L.vh_integrate(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), self.stream), "vh_integrate")
 
-    def integrate_fused(self, frame, cp, flags, lock_token):
-        check(self.L.vh_integrate_fused(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), flags, lock_token, None, self.stream),
-              "vh_integrate_fused")
+    def integrate_fused(self, frame, cp, flags, lock_token, packed_ptr=None):
+        check(self.L.vh_integrate_fused(C.byref(self.hd), C.byref(self.hp), C.byref(frame.data), C.byref(cp), flags, lock_token, None, 0,
+                                        packed_ptr, self.stream), "vh_integrate_fused")
+
+    def frame_job(self, frame, cp, bitmask_ptr=None, lock_token=T.LOCK_ENTRY, packed_ptr=None):
+        """the alloc + compactify passes of a frame as a VhFrameJob (vh_alloc_job / vh_compactify_job / the co-launches)"""
+        job = T.FrameJob()
+        C.memmove(C.byref(job.hashData), C.byref(self.hd), C.sizeof(self.hd))
+        C.memmove(C.byref(job.hashParams), C.byref(self.hp), C.sizeof(self.hp))
+        C.memmove(C.byref(job.cam), C.byref(frame.data), C.sizeof(frame.data))
+        C.memmove(C.byref(job.cp), C.byref(cp), C.sizeof(cp))
+        job.d_bitMask = bitmask_ptr
+        job.d_packedFrame = packed_ptr
+        job.lockToken = lock_token
+        return job
+
+    def alloc_job(self, job):
+        check(self.L.vh_alloc_job(C.byref(job), self.stream), "vh_alloc_job")
+
+    def compactify_job(self, job):
+        check(self.L.vh_compactify_job(C.byref(job), self.stream), "vh_compactify_job")
 
     def starve(self):
         check(self.L.vh_starve(C.byref(self.hd), C.byref(self.hp), self.stream), "vh_starve")

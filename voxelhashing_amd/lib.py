@@ -43,7 +43,9 @@ PROTOTYPES = {
     "vh_gc_identify": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _VP]),
     "vh_gc_free": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_int32, _VP]),
     "vh_bind_input_depth_color_textures": (C.c_int, [P(T.DepthCameraData)]),
-    "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP, _VP]),
+    "vh_integrate_fused": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraData), P(T.DepthCameraParams), C.c_uint32, C.c_int32, _VP, C.c_uint32, _VP, _VP]),
+    "vh_alloc_job": (C.c_int, [P(T.FrameJob), _VP]),
+    "vh_compactify_job": (C.c_int, [P(T.FrameJob), _VP]),
     "vh_render": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP]),
     "vh_ray_interval_clear": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_ray_interval_splat": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP]),
@@ -51,6 +53,8 @@ PROTOTYPES = {
     "vh_render_schedule_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "vh_render_split_tiles": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_render_intervals_co": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, P(T.FrameJob), _VP]),
+    "vh_compute_normals_co": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, P(T.FrameJob), _VP]),
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
     "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
     "vh_stream_in_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP]),
@@ -71,11 +75,12 @@ PROTOTYPES = {
     "vh_scene_rep_get_state": (C.c_int, [_VP, P(C.c_uint32)]),
     "vh_scene_rep_get_timings": (C.c_int, [_VP, P(C.c_double)]),
     "vh_scene_rep_set_options": (C.c_int, [_VP, P(T.SceneOptions)]),
-    "vh_scene_rep_integrate_ahead": (C.c_int, [_VP, _F16, P(T.DepthCameraData), P(T.DepthCameraParams), _VP]),
+    "vh_scene_rep_integrate_ahead": (C.c_int, [_VP, _F16, P(T.DepthCameraData), P(T.DepthCameraParams), _VP, P(P(T.FrameJob))]),
     "vh_scene_rep_integrate_finish": (C.c_int, [_VP, P(T.DepthCameraData), P(T.DepthCameraParams)]),
     "vh_raycast_create": (C.c_int, [P(T.RayCastParams), _VP, P(_VP)]),
     "vh_raycast_destroy": (None, [_VP]),
     "vh_raycast_render": (C.c_int, [_VP, P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _F16]),
+    "vh_raycast_render_co": (C.c_int, [_VP, P(T.HashData), P(T.HashParams), P(T.DepthCameraParams), _F16, P(T.FrameJob)]),
     "vh_raycast_get_data": (C.c_int, [_VP, P(T.RayCastData)]),
     "vh_raycast_get_params": (C.c_int, [_VP, P(T.RayCastParams)]),
     "vh_raycast_get_timings": (C.c_int, [_VP, P(C.c_double)]),
@@ -91,6 +96,7 @@ PROTOTYPES = {
     "vh_reconstruction_get_stats": (C.c_int, [_VP, P(T.ReconstructionStats)]),
     "vh_reconstruction_reset": (C.c_int, [_VP]),
     "vh_convert_color_raw_to_float4": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
+    "vh_upload_frame": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_resample_float_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_resample_float4_map": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_copy_float_map": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),

@@ -206,6 +206,21 @@ class SceneOptions(C.Structure):
     ]
 
 
+class FrameJob(C.Structure):
+    _fields_ = [
+        ("hashData", HashData),
+        ("hashParams", HashParams),
+        ("cam", DepthCameraData),
+        ("cp", DepthCameraParams),
+        ("d_bitMask", C.c_void_p),
+        ("d_packedFrame", C.c_void_p),
+        ("lockToken", C.c_int32),
+        ("allocLaunched", C.c_uint8),
+        ("compactifyLaunched", C.c_uint8),
+        ("pad0", C.c_uint8 * 2),
+    ]
+
+
 class ReconstructionOptions(C.Structure):
     _fields_ = [
         ("s_streamingEnabled", C.c_uint8),
