@@ -134,3 +134,22 @@ def test_mat4_inverse(oracle_lib):
         # rigid transform: inverse = [R^T, -R^T c]
         assert np.allclose(inv[:3, :3], m[:3, :3].T, atol=1e-6)
     assert np.array_equal(O.mat4_inverse(np.eye(4, dtype=np.float32)).reshape(4, 4), np.eye(4, dtype=np.float32))
+
+
+def test_colour_average_identity_used_by_the_hip_path():
+    """combineVoxel's colour (DSC/VoxelUtilHashSDF.h:236-240), uchar(0.5f*c0 + 0.5f*c1 + 0.5f), equals the byte-wise
+    average rounded up, (a | b) - (((a ^ b) >> 1) & 0x7f), for every pair of bytes: the HIP kernels use the integer
+    form on the packed colour word (vh_device.hpp combine_voxel)."""
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint32), np.arange(256, dtype=np.uint32), indexing="ij")
+    f = np.float32
+    ref = (f(0.5) * a.astype(np.float32) + f(0.5) * b.astype(np.float32) + f(0.5)).astype(np.float32)
+    ref = np.minimum(np.maximum(np.trunc(ref), 0), 255).astype(np.uint32)
+    got = (a | b) - (((a ^ b) >> 1) & 0x7F)
+    assert np.array_equal(ref, got)
+    # packed: three channels side by side do not disturb each other (no borrow crosses a byte: (a|b) >= ((a^b)>>1) per byte)
+    rng = np.random.default_rng(5)
+    wa, wb = rng.integers(0, 1 << 24, 100000, dtype=np.uint32), rng.integers(0, 1 << 24, 100000, dtype=np.uint32)
+    packed = (wa | wb) - (((wa ^ wb) >> 1) & 0x7F7F7F7F)
+    for sh in (0, 8, 16):
+        ca, cb = (wa >> sh) & 0xFF, (wb >> sh) & 0xFF
+        assert np.array_equal((packed >> sh) & 0xFF, (ca | cb) - (((ca ^ cb) >> 1) & 0x7F))

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Times the fused integrate kernel alone on a dense scene (S2: camera inside a 3 m sphere, 1 cm voxels, cfg3 tables):
+the scene is built with the frame loop, then vh_integrate_fused is launched back to back on the last frame's block list
+(flags 0: nothing is freed, so every launch sees the same list).  With VH_LIB_PATH set, a measurement build of the
+library is timed (voxelhashing_amd.build --out scratch/... -DVH_KNOCKOUT=n)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--scene", default="S2")
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--launches", type=int, default=200)
+    ap.add_argument("--gc", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from voxelhashing_amd import engine as E, lib, synth, vhtypes as T
+    L = lib.load()
+    cfg = dict(synth.CONFIGS[a.config], scene=a.scene)
+    hp, cp, rp = synth.config_params(cfg)
+    spheres, inside, radius = synth.scene(a.scene)
+    scene = E.CUDASceneRepHashSDF(hp, T.make_scene_options(offline=False, gc=True, starve=15))
+    frame = E.DepthFrame(cp)
+    for k in range(a.frames):
+        pose = synth.orbit_pose(k, 1000, radius)
+        E.synth_frame(spheres, inside, pose, cp, out=frame)
+        scene.integrate(pose, frame, cp, None)
+    n = scene.getNumOccupiedBlocks()
+    hd, hpp = scene.getHashData(), scene.getHashParams()
+    # the packed frame of the last integrate() is the scene's own buffer: reuse it through a job
+    job = scene.integrateAhead(pose, frame, cp, None)
+    packed = job.contents.d_packedFrame if job is not None else None
+    check = lib.check
+    check(L.vh_alloc_job(job, None), "alloc")
+    check(L.vh_compactify_job(job, None), "compactify")
+    torch.cuda.synchronize()
+    flags = 1 if a.gc else 0
+    out = {}
+    for what, pk in (("packed", packed), ("unpacked", None)):
+        for _ in range(10):
+            check(L.vh_integrate_fused(C.byref(hd), C.byref(hpp), C.byref(frame.data), C.byref(cp), flags, 12345, None, 0, pk, None), "integrate")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream().cuda_stream
+        e0.record()
+        for i in range(a.launches):
+            check(L.vh_integrate_fused(C.byref(hd), C.byref(hpp), C.byref(frame.data), C.byref(cp), flags, 20000 + i, None, 0, pk, st), "integrate")
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / a.launches
+        b = n * 8212 + 20 * cp.m_imageWidth * cp.m_imageHeight
+        out[what] = dict(us=round(us, 2), GBs=round(b / us / 1e3, 1), frac=round(b / us / 1e3 / 8000, 4))
+    st = scene.getState()
+    if st[9]:
+        out["wave0"] = dict(cycles=int(st[8]), realtime_ticks=int(st[9]), MHz=round(100.0 * st[8] / st[9], 1), rounds=int(st[10]), active_waves=int(st[11]))
+    print(json.dumps(dict(lib=os.path.basename(lib.LIB_PATH), blocks=n, **out)))
+    scene.integrateFinish(frame, cp)
+
+
+if __name__ == "__main__":
+    main()

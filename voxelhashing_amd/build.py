@@ -44,7 +44,11 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: build a variant (extra flags, e.g. -DVH_KNOCKOUT=1 for a measurement build) into another file; its objects
+    go to a directory of their own and the shipped library is left alone"""
+    if out is not None:
+        return build_variant(out, list(extra), verbose)
     if not force and up_to_date():
         return LIB
     cc = hipcc()
@@ -76,6 +80,28 @@ def build(force=False, verbose=False, extra=()):
     return LIB
 
 
+def build_variant(out, extra, verbose=False):
+    cc = hipcc()
+    objdir = out + ".objs"
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for s in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        cmd = [cc] + flags() + extra + ["-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    subprocess.check_call([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-lpthread", "-lz"])
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    if "--out" in sys.argv:  # python -m voxelhashing_amd.build --out scratch/lib_ko1.so -DVH_KNOCKOUT=1
+        print(build(out=os.path.abspath(sys.argv[sys.argv.index("--out") + 1]), extra=[a for a in sys.argv[1:] if a.startswith("-D")], verbose=True))
+    else:
+        build(force="--force" in sys.argv, verbose=True)
+        print(LIB)

@@ -518,13 +518,16 @@ VHD uint32_t pack_cw(uint32_t r, uint32_t g, uint32_t b, uint32_t w) { return r 
 VHD Vox combine_voxel(const VhHashParams& hp, Vox v0, Vox v1)
 {
     Vox out;
-    uint32_t r = f2uc((0.5f * (float)v0.r() + 0.5f * (float)v1.r()) + 0.5f);
-    uint32_t g = f2uc((0.5f * (float)v0.g() + 0.5f * (float)v1.g()) + 0.5f);
-    uint32_t b = f2uc((0.5f * (float)v0.b() + 0.5f * (float)v1.b()) + 0.5f);
+    // colour :236-240: uchar(0.5f * c0 + 0.5f * c1 + 0.5f) per channel.  For bytes c0, c1 every term and sum is exact in
+    // fp32 (half-integers up to 255.5), so the value is floor((c0 + c1) / 2 + 1/2) = (c0 + c1 + 1) >> 1, the byte-wise
+    // average rounded up: (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f) on the packed word, all channels at once
+    // (tests/test_oracle_math.py checks the identity for all 65 536 pairs against the float formula).
+    const uint32_t a = v0.cw & 0x00ffffffu, c = v1.cw & 0x00ffffffu;
+    const uint32_t rgb = (a | c) - (((a ^ c) >> 1) & 0x7f7f7f7fu);
     float w0 = (float)v0.weight(), w1 = (float)v1.weight();
     out.sdf = (v0.sdf * w0 + v1.sdf * w1) / (w0 + w1);
     uint32_t w = min(hp.m_integrationWeightMax, v0.weight() + v1.weight());
-    out.cw = pack_cw(r, g, b, w & 0xffu);
+    out.cw = rgb | ((w & 0xffu) << 24);
     return out;
 }
 

@@ -387,87 +387,255 @@ __global__ __launch_bounds__(256) void k_integrate(VhHashData hd, VhHashParams h
     }
 }
 
-// integrate_voxel on a frame packed by alloc_tile / pack_pixel: one 8-byte gather per voxel
-VHD Vox integrate_voxel_packed(const VhHashParams& hp, const VhDepthCameraParams& cp, const uint2* packed, I3 pi, Vox stored)
+// integrate_voxel on a frame packed by alloc_tile / pack_pixel, in two steps: where the voxel projects to, and what
+// the pixel found there makes of the stored voxel
+VHD bool project_voxel(const VhHashParams& hp, const VhDepthCameraParams& cp, I3 pi, uint32_t& sx, uint32_t& sy, float& pz)
 {
     F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pi));
-    const uint32_t sx = (uint32_t)f2i((pf.x * cp.fx / pf.z + cp.mx) + 0.5f);
-    const uint32_t sy = (uint32_t)f2i((pf.y * cp.fy / pf.z + cp.my) + 0.5f);
-    if (sx < cp.m_imageWidth && sy < cp.m_imageHeight) {
-        const uint2 px = packed[sy * cp.m_imageWidth + sx];
-        if ((px.y >> 24) != 0u) { // a sample: valid depth within the integration distance, valid colour
-            const float depth = __uint_as_float(px.x);
-            float sdf = depth - pf.z;
-            const float truncation = get_truncation(hp, depth);
-            if (sdf > -truncation) {
-                if (sdf >= 0.0f) sdf = fminf(truncation, sdf);
-                else sdf = fmaxf(-truncation, sdf);
-                Vox curr;
-                curr.sdf = sdf;
-                curr.cw = px.y;
-                return combine_voxel(hp, stored, curr);
-            }
+    sx = (uint32_t)f2i((pf.x * cp.fx / pf.z + cp.mx) + 0.5f);
+    sy = (uint32_t)f2i((pf.y * cp.fy / pf.z + cp.my) + 0.5f);
+    pz = pf.z;
+    return sx < cp.m_imageWidth && sy < cp.m_imageHeight;
+}
+VHD Vox apply_pixel(const VhHashParams& hp, uint2 px, float pz, Vox stored)
+{
+    if ((px.y >> 24) != 0u) { // a sample: valid depth within the integration distance, valid colour
+        const float depth = __uint_as_float(px.x);
+        float sdf = depth - pz;
+        const float truncation = get_truncation(hp, depth);
+        if (sdf > -truncation) {
+            if (sdf >= 0.0f) sdf = fminf(truncation, sdf);
+            else sdf = fmaxf(-truncation, sdf);
+            Vox curr;
+            curr.sdf = sdf;
+            curr.cw = px.y;
+            return combine_voxel(hp, stored, curr);
         }
     }
     return stored;
 }
+VHD Vox integrate_voxel_packed(const VhHashParams& hp, const VhDepthCameraParams& cp, const uint2* packed, I3 pi, Vox stored)
+{
+    uint32_t sx, sy;
+    float pz;
+    if (project_voxel(hp, cp, pi, sx, sy, pz)) return apply_pixel(hp, packed[sy * cp.m_imageWidth + sx], pz, stored);
+    return stored;
+}
 
-// The fused pass, one WAVE per SDF block: a block is 4 KB, four 16-byte loads per lane, all in flight before the first
-// is used (load j of lane l holds voxels 128 j + 2 l and + 1: x = 2l mod 8 (+1), y = (l / 4) mod 8, z = 2j + l / 32);
-// min |sdf| / max weight of the block are a wave reduction (no LDS, no barrier), lane 0 edits the table for a block
-// that garbage collection frees.  The grid is persistent (the block count lives on the device); wave w of workgroup g
-// takes blocks w * gridDim + g, + 4 gridDim, ...: a frame with few blocks spreads them over all compute units.
+// The fused pass: integrate -> starve -> identify -> free with every voxel read once and written once.  The block count
+// lives on the device (no host round trip), so the grid is fixed and the kernel picks its shape from the count:
+//   * few blocks (count <= workgroups): one WORKGROUP per block, two x-adjacent voxels (16 B) per lane -- the frame is
+//     a latency chain (entry -> voxels -> gather -> table edit), and four waves per block keep it short;
+//   * many blocks: one WAVE per block (4 KB = four 16-byte loads per lane), A = ceil(count / r) waves taking r blocks
+//     each (r = ceil(count / 5120): at most five waves per SIMD, all with the same load; the active waves fill whole
+//     workgroups).  min |sdf| / max weight are a wave reduction (no LDS, no barrier); lane 0 edits the table; the
+//     block's screen footprint is staged in LDS (below).
+// Load j of lane l of a wave that holds a whole block: voxels 128 j + 2 l and + 1, i.e. x = 2l mod 8 (+1),
+// y = (l / 4) mod 8, z = 2j + l / 32 (delinearizeVoxelIndex, DSC/VoxelUtilHashSDF.h:313-318).
+template <bool PACKED>
+VHD void integrate_pair(const VhHashParams& hp, const VhDepthCameraParams& cp, const VhDepthCameraData& cam, const uint2* packed,
+                        uint32_t flags, I3 p0, uint4& raw, float& minSdf, uint32_t& maxW)
+{
+    Vox v0 = unpack_vox(make_uint2(raw.x, raw.y)), v1 = unpack_vox(make_uint2(raw.z, raw.w));
+    if (PACKED) {
+        v0 = integrate_voxel_packed(hp, cp, packed, p0, v0);
+        v1 = integrate_voxel_packed(hp, cp, packed, mki3(p0.x + 1, p0.y, p0.z), v1);
+    } else {
+        v0 = integrate_voxel(hp, cp, cam, p0, v0);
+        v1 = integrate_voxel(hp, cp, cam, mki3(p0.x + 1, p0.y, p0.z), v1);
+    }
+    // Pin the result words in VGPRs here.  Without this, hipcc (ROCm 7.2, gfx950, -O3) merges the "not integrated" path
+    // of the second voxel with a register that the gather has already overwritten (found by the parity tests: sdf of
+    // skipped odd voxels came back as the colour's MINF).
+    asm volatile("" : "+v"(v0.sdf), "+v"(v0.cw), "+v"(v1.sdf), "+v"(v1.cw));
+    if (flags & VH_FUSED_STARVE) { v0 = starve_voxel(v0); v1 = starve_voxel(v1); }
+    minSdf = fminf(minSdf, fminf(gc_key(v0), gc_key(v1)));
+    maxW = max(maxW, max(v0.weight(), v1.weight()));
+    const uint2 a = pack_vox(v0), c = pack_vox(v1);
+    raw = make_uint4(a.x, a.y, c.x, c.y);
+}
+
+constexpr uint32_t kIntegrateWavesMost = 5120; // waves that take blocks when there are many: five per SIMD
+constexpr uint32_t kIntegrateTile = 32;        // a block's screen footprint of up to 32 x 30 pixels is staged in LDS,
+constexpr uint32_t kIntegrateTileRows = 30;    // rows 34 pixels apart (272 B: vertical neighbours fall into different banks):
+constexpr uint32_t kIntegrateTileStride = 34;  // just under 32 KB per workgroup, five workgroups per compute unit
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, VhDepthCameraParams cp,
                                                          uint32_t flags, int32_t lockToken, uint32_t* countMirror, uint32_t mirrorTag,
                                                          const uint2* packed)
 {
+    __shared__ float sMin[4];
+    __shared__ uint32_t sMax[4];
+    __shared__ int sFreed;
+    __shared__ __attribute__((aligned(16))) uint2 sTile[PACKED ? 256 / kWave : 1][PACKED ? kIntegrateTileRows * kIntegrateTileStride : 2];
     const uint32_t lane = lane_id();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const uint32_t nWaves = gridDim.x * (blockDim.x / kWave);
-    uint32_t b = wave * gridDim.x + blockIdx.x;
-    // the count and this wave's first entry in one trip (the list is Ne entries long: reading beyond the count is
-    // reading stale entries, which are not used)
+    const uint32_t nEntries = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    // the count and the entry this workgroup / wave would start with in one trip (the list is Ne entries long: reading
+    // beyond the count is reading stale entries, which are not used)
     const uint32_t count = (uint32_t)hd.d_hashCompactifiedCounter[0];
-    int4 q = make_int4(0, 0, 0, 0);
-    if (b < hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) q = load_quad(&hd.d_hashCompactified[b]);
+    // first block of this wave when waves take blocks: the active waves fill whole workgroups (the others leave at
+    // once and free their slot: a workgroup's LDS and registers are held until its last wave is done)
+    const uint32_t wFirst = blockIdx.x * (256u / kWave) + wave;
+    int4 qg = make_int4(0, 0, 0, 0), qw = make_int4(0, 0, 0, 0);
+    if (blockIdx.x < nEntries) qg = load_quad(&hd.d_hashCompactified[blockIdx.x]);
+    if (wFirst < nEntries) qw = load_quad(&hd.d_hashCompactified[wFirst]);
     // host-visible copy of the block count and the caller's tag (mapped pinned memory): replaces a per-frame
     // device->host copy, and lets the host see how far the device has come
     if (countMirror && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint2*>(countMirror) = make_uint2(count, mirrorTag);
-    const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
     const float thr = get_truncation(hp, cp.m_sensorDepthWorldMax);
 
-    while (b < count) {
+    if (count <= gridDim.x) {
+        // ---- one workgroup per block
+        const uint32_t b = blockIdx.x;
+        if (b >= count) return;
+        const uint32_t t = threadIdx.x;
+        const int ex = __builtin_amdgcn_readfirstlane(qg.x), ey = __builtin_amdgcn_readfirstlane(qg.y);
+        const int ez = __builtin_amdgcn_readfirstlane(qg.z), ptr = __builtin_amdgcn_readfirstlane(qg.w);
+        uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + t;
+        uint4 raw = *vp;
+        // voxel pair (2t, 2t+1): x = (2t)%8 (+1), y = (2t%64)/8, z = 2t/64
+        const I3 p0 = mki3(ex * VH_SDF_BLOCK_SIZE + (int)((2u * t) & 7u), ey * VH_SDF_BLOCK_SIZE + (int)(((2u * t) & 63u) >> 3), ez * VH_SDF_BLOCK_SIZE + (int)((2u * t) >> 6));
+        float minSdf = pinf();
+        uint32_t maxW = 0u;
+        integrate_pair<PACKED>(hp, cp, cam, packed, flags, p0, raw, minSdf, maxW);
+        if (flags & VH_FUSED_GC) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                minSdf = fminf(minSdf, __shfl_xor(minSdf, o));
+                maxW = max(maxW, (uint32_t)__shfl_xor((int)maxW, o));
+            }
+            if (lane == 0) { sMin[wave] = minSdf; sMax[wave] = maxW; }
+            __syncthreads();
+            minSdf = fminf(fminf(sMin[0], sMin[1]), fminf(sMin[2], sMin[3]));
+            maxW = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
+            const bool decide = (minSdf >= thr) || (maxW == 0u); // the same in every thread of the workgroup
+            if (t == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
+            if (decide) {
+                if (t == 0) sFreed = delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), lockToken) ? 1 : 0;
+                __syncthreads();
+                if (sFreed != 0) raw = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        *vp = raw;
+        return;
+    }
+
+    // ---- one wave per block, `rounds` blocks per wave
+    const uint32_t rounds = (count + kIntegrateWavesMost - 1u) / kIntegrateWavesMost;
+    const uint32_t nActive = (count + rounds - 1u) / rounds; // <= kIntegrateWavesMost <= the waves of the grid
+    if (wFirst >= nActive) return;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9 // measurement build: shader clock over one wave's lifetime
+    const uint64_t stampC0 = __builtin_amdgcn_s_memtime(), stampR0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
+    uint32_t b = wFirst;
+    int4 q = qw;
+    uint2* tile = sTile[wave];
+    for (;;) {
         const int ex = __builtin_amdgcn_readfirstlane(q.x), ey = __builtin_amdgcn_readfirstlane(q.y);
         const int ez = __builtin_amdgcn_readfirstlane(q.z), ptr = __builtin_amdgcn_readfirstlane(q.w);
         uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + lane;
         uint4 raw[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) raw[j] = vp[j * kWave];
-        const uint32_t bNext = b + nWaves;
-        if (bNext < count) q = load_quad(&hd.d_hashCompactified[bNext]); // the next block's entry behind this block's voxels
+        const bool hasNext = b + nActive < count;
+        if (hasNext) q = load_quad(&hd.d_hashCompactified[b + nActive]); // the next block's entry behind this block's voxels
+        // (Requesting the next block's voxels here as well was measured: slower.  The waves do not wait for the stream --
+        // the kernel is bound by instruction issue, ~1000 vector instructions per block at 4 cycles each.)
 
         float minSdf = pinf();
         uint32_t maxW = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            Vox v0 = unpack_vox(make_uint2(raw[j].x, raw[j].y)), v1 = unpack_vox(make_uint2(raw[j].z, raw[j].w));
-            const I3 p0 = mki3(ex * VH_SDF_BLOCK_SIZE + lx, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0);
-            if (PACKED) {
-                v0 = integrate_voxel_packed(hp, cp, packed, p0, v0);
-                v1 = integrate_voxel_packed(hp, cp, packed, mki3(p0.x + 1, p0.y, p0.z), v1);
-            } else {
-                v0 = integrate_voxel(hp, cp, cam, p0, v0);
-                v1 = integrate_voxel(hp, cp, cam, mki3(p0.x + 1, p0.y, p0.z), v1);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 1 // measurement build: the voxel stream alone (read, write back)
+        if (false) {
+#else
+        if (PACKED) {
+#endif
+            // A voxel's gather from the frame is one cache access per LANE -- 64 tag look-ups per wave instruction, the
+            // bound of this shape before staging (1 cm voxels: 13 us of a 33 us launch).  So the block's screen
+            // footprint is staged in LDS first, four image rows per load instruction (whole lines), while the voxel
+            // loads are in flight: the box of the eight corner voxels' pixels, one pixel wider all round (a perspective
+            // projection maps the block into the hull of its corners when all of them lie in front of the camera; the
+            // extra pixel covers the rounding of the per-voxel arithmetic).  A voxel that projects outside the staged
+            // box all the same is gathered from the frame itself: the box decides where a pixel is read, never which.
+            int cx, cy;
+            float cz;
+            {
+                const uint32_t c = lane & 7u;
+                const I3 pc = mki3(ex * VH_SDF_BLOCK_SIZE + ((c & 1u) ? 7 : 0), ey * VH_SDF_BLOCK_SIZE + ((c & 2u) ? 7 : 0), ez * VH_SDF_BLOCK_SIZE + ((c & 4u) ? 7 : 0));
+                uint32_t ux, uy;
+                (void)project_voxel(hp, cp, pc, ux, uy, cz);
+                cx = (int)ux; cy = (int)uy;
             }
-            // Pin the result words in VGPRs here (see k_integrate: hipcc merged the "not integrated" path of a voxel with a
-            // register the gather had already overwritten).
-            asm volatile("" : "+v"(v0.sdf), "+v"(v0.cw), "+v"(v1.sdf), "+v"(v1.cw));
-            if (flags & VH_FUSED_STARVE) { v0 = starve_voxel(v0); v1 = starve_voxel(v1); }
-            minSdf = fminf(minSdf, fminf(gc_key(v0), gc_key(v1)));
-            maxW = max(maxW, max(v0.weight(), v1.weight()));
-            const uint2 a = pack_vox(v0), c = pack_vox(v1);
-            raw[j] = make_uint4(a.x, a.y, c.x, c.y);
+            int bx0 = cx, bx1 = cx, by0 = cy, by1 = cy;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                bx0 = min(bx0, __shfl_xor(bx0, o)); bx1 = max(bx1, __shfl_xor(bx1, o));
+                by0 = min(by0, __shfl_xor(by0, o)); by1 = max(by1, __shfl_xor(by1, o));
+                cz = fminf(cz, __shfl_xor(cz, o));
+            }
+            bx0 = __builtin_amdgcn_readfirstlane(bx0); bx1 = __builtin_amdgcn_readfirstlane(bx1);
+            by0 = __builtin_amdgcn_readfirstlane(by0); by1 = __builtin_amdgcn_readfirstlane(by1);
+            const bool inFront = __builtin_amdgcn_readfirstlane(cz > 1e-3f ? 1 : 0) != 0;
+            // one pixel of margin, clipped to the image (coordinates beyond +-2^30 would overflow the arithmetic below:
+            // such a block is simply not staged); the box starts at an even pixel: rows are staged two pixels per lane
+            const bool sane = bx0 > -(1 << 30) && bx1 < (1 << 30) && by0 > -(1 << 30) && by1 < (1 << 30);
+            const int x0i = max(bx0 - 1, 0) & ~1, x1i = min(bx1 + 1, (int)cp.m_imageWidth - 1);
+            const int y0i = max(by0 - 1, 0), y1i = min(by1 + 1, (int)cp.m_imageHeight - 1);
+            const bool staged = inFront && sane && x0i <= x1i && y0i <= y1i && (x1i - x0i) < (int)kIntegrateTile && (y1i - y0i) < (int)kIntegrateTileRows &&
+                                (cp.m_imageWidth & 1u) == 0u;
+            const uint32_t x0 = (uint32_t)x0i, y0 = (uint32_t)y0i;
+            const uint32_t w = staged ? (uint32_t)(x1i - x0i + 1) : 0u, h = staged ? (uint32_t)(y1i - y0i + 1) : 0u;
+            if (staged) {
+                // lane -> (row r + lane / 16, pixels 2 (lane % 16) and + 1): four rows per load instruction.  An even image
+                // width and an even x0 keep a pixel pair inside its row.
+                const uint32_t col2 = (lane & 15u) * 2u, rowInQuad = lane >> 4;
+                const uint4* src = reinterpret_cast<const uint4*>(packed + (size_t)(y0 + rowInQuad) * cp.m_imageWidth + x0 + col2);
+                uint4* dst = reinterpret_cast<uint4*>(tile + rowInQuad * kIntegrateTileStride + col2);
+                __builtin_amdgcn_wave_barrier(); // the previous block's reads of the tile are done (they fed its stores)
+#pragma unroll 4
+                for (uint32_t r = 0; r < h; r += 4u) {
+                    if (r + rowInQuad < h && col2 < w) dst[(size_t)r * (kIntegrateTileStride / 2u)] = src[(size_t)r * (cp.m_imageWidth / 2u)];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                Vox v[2] = { unpack_vox(make_uint2(raw[j].x, raw[j].y)), unpack_vox(make_uint2(raw[j].z, raw[j].w)) };
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    uint32_t sx, sy;
+                    float pz;
+                    if (project_voxel(hp, cp, mki3(ex * VH_SDF_BLOCK_SIZE + lx + k, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0), sx, sy, pz)) {
+                        const uint32_t tx = sx - x0, ty = sy - y0; // unsigned: a pixel left of / above the box wraps to a huge number
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 2 // measurement build: projection only
+                        v[k].cw ^= (tx + ty + __float_as_uint(pz)) & 1u;
+#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 3 // measurement build: projection + the pixel, no blend
+                        const uint2 px = (tx < w && ty < h) ? tile[ty * kIntegrateTileStride + tx] : packed[sy * cp.m_imageWidth + sx];
+                        v[k].cw ^= (px.x + px.y + __float_as_uint(pz)) & 1u;
+#else
+                        const uint2 px = (tx < w && ty < h) ? tile[ty * kIntegrateTileStride + tx] : packed[sy * cp.m_imageWidth + sx];
+                        v[k] = apply_pixel(hp, px, pz, v[k]);
+#endif
+                    }
+                }
+                asm volatile("" : "+v"(v[0].sdf), "+v"(v[0].cw), "+v"(v[1].sdf), "+v"(v[1].cw)); // see integrate_pair
+                if (flags & VH_FUSED_STARVE) { v[0] = starve_voxel(v[0]); v[1] = starve_voxel(v[1]); }
+                minSdf = fminf(minSdf, fminf(gc_key(v[0]), gc_key(v[1])));
+                maxW = max(maxW, max(v[0].weight(), v[1].weight()));
+                const uint2 a = pack_vox(v[0]), c = pack_vox(v[1]);
+                raw[j] = make_uint4(a.x, a.y, c.x, c.y);
+            }
+        } else {
+#if !(defined(VH_KNOCKOUT) && VH_KNOCKOUT == 1)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                integrate_pair<PACKED>(hp, cp, cam, packed, flags, mki3(ex * VH_SDF_BLOCK_SIZE + lx, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0),
+                                       raw[j], minSdf, maxW);
+#endif
         }
         bool freed = false;
         if (flags & VH_FUSED_GC) {
@@ -486,8 +654,15 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) vp[j * kWave] = freed ? make_uint4(0u, 0u, 0u, 0u) : raw[j];
-        b = bNext;
+        if (!hasNext) break;
+        b += nActive;
     }
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9
+    if (wFirst == 0u && lane == 0u) {
+        const uint64_t c = __builtin_amdgcn_s_memtime() - stampC0, r = __builtin_amdgcn_s_memrealtime() - stampR0;
+        hd.d_state[8] = (uint32_t)c; hd.d_state[9] = (uint32_t)r; hd.d_state[10] = rounds; hd.d_state[11] = nActive;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_starve(VhHashData hd, VhHashParams hp)
@@ -2702,8 +2877,9 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
                        const void* d_packedFrame, vhStream_t stream)
 {
     if (!hd || !hp || !cam || !cp || !cam->d_depthData) return VH_ERR_BAD_ARGUMENT;
-    // persistent grid: the block count lives on the device, so no host read-back is needed.  One wave per block, four
-    // per workgroup, up to eight workgroups per compute unit.
+    if (cp->m_imageWidth > 0xffffu || cp->m_imageHeight > 0xffffu) return VH_ERR_BAD_ARGUMENT;
+    // persistent grid: the block count lives on the device, so no host read-back is needed (the kernel picks its shape
+    // from the count)
     const uint32_t want = cdiv(hp->m_numSDFBlocks, 4), most = device_num_cus() * 8u;
     const uint32_t grid = want < most ? want : most;
     const uint2* packed = reinterpret_cast<const uint2*>(d_packedFrame);

@@ -11,7 +11,8 @@ import numpy as np
 from . import vhtypes as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvoxelhashing_amd.so")
+# VH_LIB_PATH: a measurement build of the same library (voxelhashing_amd.build --out ...), for tools/ only
+LIB_PATH = os.environ.get("VH_LIB_PATH") or os.path.join(_HERE, "libvoxelhashing_amd.so")
 _LIB = None
 
 P = C.POINTER
