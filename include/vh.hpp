@@ -117,6 +117,9 @@ public:
     void integrateFinish(const DepthCameraData& depthCameraData, const DepthCameraParams& depthCameraParams);
     // frames whose pass over the voxels has started on the device (read from mapped host memory: no synchronisation)
     unsigned int getNumFramesStartedOnDevice() const;
+    // whoever edits the table outside integrate() (streaming) says so: work prepared from the table before is void
+    void noteTableEdited() { m_tableEpoch++; }
+    unsigned int getTableEpoch() const { return m_tableEpoch; }
     void setOptions(const VhSceneOptions& o) { m_options = o; }
     const VhSceneOptions& getOptions() const { return m_options; }
     vhStream_t getStream() const { return m_stream; }
@@ -146,6 +149,7 @@ private:
     bool m_occupiedPending;   // a frame was enqueued since the host value was last known exact
     bool m_counterCleared;    // d_hashCompactifiedCounter is known to be 0 (k_alloc clears it)
     VhStageTimer* m_timer;
+    unsigned int m_tableEpoch;
     VhFrameJob m_job;         // alloc + compactify of the frame in progress
     int m_aheadPending;       // 0 none, 1 job prepared by integrateAhead()
     void* d_packedFrame;      // the frame as the alloc pass packs it for the pass over the voxels (8 bytes per pixel)
@@ -194,6 +198,13 @@ private:
     uint32_t* d_schedule;      // tiles by cost class, for the launch order of the next render()
     uint32_t m_phase;          // render() calls with intervals so far
     bool m_useIntervals;
+    // the interval splat of the next render, made ahead inside this render's computeNormals launch (vh_compute_normals_co2)
+    struct PreSplat {
+        bool valid;
+        float pose[16];         // the pose it was made for
+        const void* table;      // d_hash of the scene
+        uint32_t frameNumber, tableEpoch, phase, capacity;
+    } m_preSplat;
 };
 
 // ---------------------------------------------------------------------------

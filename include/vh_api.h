@@ -153,6 +153,14 @@ int vh_render_intervals_co(const VhHashData* hd, const VhHashParams* hp, const V
                            const VhRayCastParams* rp, uint32_t* d_tileHeads, const VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
                            uint32_t* d_schedule, uint32_t phase, VhFrameJob* job, vhStream_t stream);
 int vh_compute_normals_co(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* job, vhStream_t stream);
+/* ... and, when the job's compactify pass rides along and nextView != NULL, the interval splat of the NEXT render as
+ * well (arguments as vh_ray_interval_splat; nextView holds that render's view matrices: the pose of the job's frame).
+ * It lists the table as it stands BEFORE the job's frame is integrated: blocks that pass frees stay listed with all-zero
+ * voxels (read like absent ones), blocks allocated later are empty.  Whoever uses it must make sure nothing else edits
+ * the table in between (the host class CUDARayCastSDF checks the job's frame number and table epoch). */
+int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* job,
+                           const VhRayCastParams* nextView, uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                           uint32_t* d_schedule, uint32_t phase, uint32_t* d_longestList, vhStream_t stream);
 
 /* ---- streaming launchers: DSC/CUDASceneRepChunkGrid.h:142-146 --------------- */
 /* integrateFromGlobalHashPass1CUDA(params, hashData, threadsPerPart, start, radius, camPos,

@@ -224,6 +224,8 @@ typedef struct VhFrameJob {
     void* d_packedFrame;     /* width*height*8 bytes, written by the alloc pass (see vh_alloc_job), or NULL */
     int32_t lockToken;
     uint8_t allocLaunched, compactifyLaunched, pad0[2];
+    uint32_t frameNumber; /* frames the scene had integrated when the job was made */
+    uint32_t tableEpoch;  /* bumped by everything that edits the table outside integrate(): reset, streaming */
 } VhFrameJob;
 
 /* The switches reconstruction() reads (DSC/DepthSensing.cpp:720-924) when it runs headless over a recorded sequence at

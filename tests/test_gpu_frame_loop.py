@@ -139,6 +139,46 @@ def test_co_launch_through_the_host_classes(E, oracle_lib):
             scene.integrateFinish(frames[0], cp)  # nothing pending
 
 
+def test_splat_made_ahead_is_dropped_when_the_table_changes(E, oracle_lib):
+    """render(..., job) also makes the NEXT render's interval splat (inside its computeNormals launch).  That splat is
+    used only by a render for the very pose, table and frame it was made for: a reset, an extra integrate, another
+    pose or a render without a job in between must fall back to a fresh splat, and the maps must be the oracle's."""
+    O = oracle_lib
+    hp, cp, rp = small_config(160, 120, num_buckets=1 << 17, num_sdf_blocks=1 << 12)
+    poses = [shifted_pose(k, 90) for k in range(8)]
+    frames, host = make_inputs(E, O, cp, poses, SHIFTED_S1, 0)
+    opt = T.make_scene_options(offline=False, gc=True, starve=3)
+    scene, ray, ref = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp), O.OracleScene(hp, cp, rp, opt)
+
+    def frame(k, render_pose=None, use_job=True):
+        job = scene.integrateAhead(poses[k], frames[k], cp, None)
+        if render_pose is not None:
+            ray.render(scene.getHashData(), scene.getHashParams(), cp, render_pose, coLaunch=job if use_job else None)
+            assert_maps_equal(ray.download(), ref.render(render_pose), f"frame {k}")
+        scene.integrateFinish(frames[k], cp)
+        ref.integrate(poses[k], host[k][0], host[k][1])
+        canonical.assert_same_scene(scene.state(), ref.state(), f"frame {k}")
+
+    frame(0)
+    frame(1, poses[0])               # makes the splat for pose 1 ahead
+    frame(2, poses[1])               # uses it, makes the one for pose 2
+    frame(3, poses[0])               # another pose than the splat was made for: dropped
+    frame(4, poses[3], use_job=False)  # no job: a fresh splat, nothing made ahead
+    frame(5, poses[4])               # makes the one for pose 5
+    scene.integrate(poses[6], frames[6], cp, None)  # an extra frame in between: the frame number no longer fits
+    ref.integrate(poses[6], host[6][0], host[6][1])
+    frame(7, poses[6])
+    # a reset in between
+    job = scene.integrateAhead(poses[0], frames[0], cp, None)
+    ray.render(scene.getHashData(), scene.getHashParams(), cp, poses[7], coLaunch=job)
+    scene.integrateFinish(frames[0], cp)
+    scene.reset()
+    ref.reset()
+    frame(0)
+    frame(1, poses[0])
+    assert (ray.download()["depth"] != -np.inf).sum() > 500
+
+
 def test_invalid_pose_is_skipped_and_loop_can_restart(E, oracle_lib):
     """DSC/DepthSensing.cpp:738-741: a frame whose recorded pose starts with -inf / NaN is not processed"""
     O = oracle_lib

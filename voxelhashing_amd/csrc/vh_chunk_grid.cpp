@@ -385,6 +385,7 @@ void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, f
     HashData& hd = m_sceneRepHashSDF->getHashData();
     vhStream_t stream = m_sceneRepHashSDF->getStream();
     const int32_t token = m_sceneRepHashSDF->nextLockToken(); // = resetHashBucketMutexCUDA
+    m_sceneRepHashSDF->noteTableEdited();
     check(vh_memset(d_SDFBlockCounter, 0, sizeof(unsigned int), stream), "clearSDFBlockCounter");
 
     const unsigned int numEntries = hp.m_hashNumBuckets * hp.m_hashBucketSize;
@@ -534,6 +535,7 @@ void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
             throw vh::Error(VH_ERR_HEAP_EXHAUSTED, "stream-in: not enough free SDF blocks");
         }
         const int32_t token = m_sceneRepHashSDF->nextLockToken();
+        m_sceneRepHashSDF->noteTableEdited();
         check(vh_stream_in_pass1(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, token, stream), "chunkToGlobalHashPass1CUDA");
         check(vh_stream_in_pass2(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, (const VhVoxel*)d_SDFBlockInput, stream), "chunkToGlobalHashPass2CUDA");
         // update heap counter (pinned source: stays valid until the copy ran)

@@ -282,6 +282,7 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
     m_counterCleared = false;
     m_timer = new VhStageTimer(3);
     m_aheadPending = 0;
+    m_tableEpoch = 0;
     d_packedFrame = nullptr;
     m_packedPixels = 0;
     std::memset(&m_job, 0, sizeof(m_job));
@@ -314,6 +315,7 @@ void CUDASceneRepHashSDF::reset()
     std::memcpy(m_hashParams.m_rigidTransform, id.m, sizeof(id.m));
     std::memcpy(m_hashParams.m_rigidTransformInverse, id.m, sizeof(id.m));
     m_aheadPending = 0;
+    m_tableEpoch++;
     m_occupiedPending = true; // reset() waits for the device before it clears the mapped words
     pollOccupiedCount(true);
     h_occupied[0] = h_occupied[1] = 0;
@@ -414,6 +416,8 @@ void CUDASceneRepHashSDF::prepareJob(const DepthCameraData& cam, const DepthCame
     m_job.d_bitMask = d_bitMask;
     m_job.d_packedFrame = d_packedFrame;
     m_job.lockToken = nextLockToken();
+    m_job.frameNumber = m_numIntegratedFrames;
+    m_job.tableEpoch = m_tableEpoch;
 }
 
 // DSC/CUDASceneRepHashSDF.h:64-83
@@ -656,6 +660,7 @@ CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
     check(vh_ray_interval_clear(d_tileHeads, params.m_width, params.m_height, m_stream), "vh_ray_interval_clear");
     d_schedule = nullptr;
     m_phase = 0;
+    std::memset(&m_preSplat, 0, sizeof(m_preSplat));
     const size_t schedBytes = vh_render_schedule_bytes(params.m_width, params.m_height);
     checkHip(hipMalloc((void**)&d_schedule, schedBytes), "render schedule");
     checkHip(hipMemsetAsync(d_schedule, 0, schedBytes, (hipStream_t)m_stream), "render schedule");
@@ -713,7 +718,22 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     // an event record idles the queue for a few microseconds: with a stride only every n-th call is timed
     const bool timed = m_timer && (m_renderCalls++ % m_timeStride) == 0;
     const bool timedAll = timed && !m_timeMarchOnly;
-    if (m_useIntervals) {
+    // Was this render's splat made ahead, inside the previous render's computeNormals launch?  Only if it is for this
+    // very pose and table, the scene has integrated exactly the one frame it was made before, and nothing else has
+    // edited the table since.
+    const bool preSplatted = m_useIntervals && m_preSplat.valid && coLaunch && m_preSplat.table == (const void*)hashData.d_hash &&
+                             coLaunch->frameNumber == m_preSplat.frameNumber + 1u && coLaunch->tableEpoch == m_preSplat.tableEpoch &&
+                             std::memcmp(m_preSplat.pose, lastRigidTransform.m, sizeof(m_preSplat.pose)) == 0;
+    if (m_preSplat.valid && !preSplatted) {
+        // a splat made ahead that this call cannot use: its tile heads and lists must not leak into the fresh one
+        check(vh_ray_interval_clear(d_tileHeads, m_params.m_width, m_params.m_height, m_stream), "vh_ray_interval_clear");
+        m_phase = m_preSplat.phase;
+    }
+    m_preSplat.valid = false;
+    if (preSplatted) {
+        m_phase = m_preSplat.phase;
+        m_tileCapacity = m_preSplat.capacity;
+    } else if (m_useIntervals) {
         if (timedAll) m_timer->start(ST_SPLAT, (hipStream_t)m_stream);
         ++m_phase;
         // Table size for this frame, from what the ray caster reported two frames ago (mapped host word, no
@@ -744,7 +764,31 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     if (timed) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {
         if (timedAll) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
-        check(vh_compute_normals_co(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, coLaunch, m_stream), "computeNormals");
+        // With a job riding along, the NEXT render's splat rides too: that render's pose is the job's (the pose of
+        // the frame being integrated), and the table it will see differs from the one listed here only by what the
+        // frame's pass over the voxels frees and what the next alloc adds (vh_compute_normals_co2).
+        const bool ahead = m_useIntervals && coLaunch && coLaunch->allocLaunched && !coLaunch->compactifyLaunched &&
+                           coLaunch->hashData.d_hash == hashData.d_hash;
+        if (ahead) {
+            RayCastParams next = m_params;
+            std::memcpy(next.m_viewMatrix, coLaunch->hashParams.m_rigidTransformInverse, sizeof(next.m_viewMatrix));
+            std::memcpy(next.m_viewMatrixInverse, coLaunch->hashParams.m_rigidTransform, sizeof(next.m_viewMatrixInverse));
+            const uint32_t longest = *(volatile uint32_t*)h_longestList;
+            if (longest > (uint32_t)VH_TILE_LIST_CAPACITY) { m_largeTables = true; m_quietFrames = 0; }
+            else if (m_largeTables && ++m_quietFrames > 30) m_largeTables = false;
+            const uint32_t capacity = m_largeTables ? VH_TILE_LIST_CAPACITY_LARGE : VH_TILE_LIST_CAPACITY;
+            check(vh_compute_normals_co2(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, coLaunch, &next, d_tileHeads, d_tileBlocks,
+                                         capacity, d_schedule, m_phase + 1u, d_longestList, m_stream), "computeNormals");
+            m_preSplat.valid = true;
+            std::memcpy(m_preSplat.pose, coLaunch->hashParams.m_rigidTransform, sizeof(m_preSplat.pose));
+            m_preSplat.table = (const void*)hashData.d_hash;
+            m_preSplat.frameNumber = coLaunch->frameNumber;
+            m_preSplat.tableEpoch = coLaunch->tableEpoch;
+            m_preSplat.phase = m_phase + 1u;
+            m_preSplat.capacity = capacity;
+        } else {
+            check(vh_compute_normals_co(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, coLaunch, m_stream), "computeNormals");
+        }
         if (timedAll) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
     }
 }

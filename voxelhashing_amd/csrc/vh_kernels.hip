@@ -399,20 +399,23 @@ VHD bool project_voxel(const VhHashParams& hp, const VhDepthCameraParams& cp, I3
 }
 VHD Vox apply_pixel(const VhHashParams& hp, uint2 px, float pz, Vox stored)
 {
-    if ((px.y >> 24) != 0u) { // a sample: valid depth within the integration distance, valid colour
-        const float depth = __uint_as_float(px.x);
-        float sdf = depth - pz;
-        const float truncation = get_truncation(hp, depth);
-        if (sdf > -truncation) {
-            if (sdf >= 0.0f) sdf = fminf(truncation, sdf);
-            else sdf = fmaxf(-truncation, sdf);
-            Vox curr;
-            curr.sdf = sdf;
-            curr.cw = px.y;
-            return combine_voxel(hp, stored, curr);
-        }
-    }
-    return stored;
+    // Without branches: every lane forms the blend, a select keeps or drops it (the lanes of a wave rarely agree, and
+    // straight-line code lets the eight voxels of a lane overlap: measured 6 % on the dense scene).  The arithmetic of a
+    // kept blend is integrateDepthMapKernel's (:447-472); a dropped one may be anything, NaN included.
+    const float depth = __uint_as_float(px.x);
+    float sdf = depth - pz;
+    const float truncation = get_truncation(hp, depth);
+    // a sample: valid depth within the integration distance, valid colour (weight byte, pack_pixel), not behind the band
+    const bool use = ((px.y >> 24) != 0u) && (sdf > -truncation);
+    const float lo = fmaxf(-truncation, sdf), hi = fminf(truncation, sdf);
+    Vox curr;
+    curr.sdf = (sdf >= 0.0f) ? hi : lo;
+    curr.cw = px.y;
+    const Vox c = combine_voxel(hp, stored, curr);
+    Vox out;
+    out.sdf = use ? c.sdf : stored.sdf;
+    out.cw = use ? c.cw : stored.cw;
+    return out;
 }
 VHD Vox integrate_voxel_packed(const VhHashParams& hp, const VhDepthCameraParams& cp, const uint2* packed, I3 pi, Vox stored)
 {
@@ -853,13 +856,21 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
     }
 }
 
-__global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
-                                                        VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap,
-                                                        uint32_t* sched, uint32_t phase, uint32_t numCUs, uint32_t nSplatGroups, uint32_t* feedback)
+struct SplatShared {
+    uint32_t sBuckets[kSplatWordsPerGroup * 32];
+    int4 sBlocks[kSplatQueue];
+    uint32_t sNumBuckets, sNumBlocks;
+};
+
+// one workgroup of the splat: `group` < nSplatGroups takes 32 occupancy words, group == nSplatGroups makes the schedule
+__device__ void interval_splat_group(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
+                                     uint4* heads, int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase, uint32_t numCUs,
+                                     uint32_t nSplatGroups, uint32_t* feedback, uint32_t group, SplatShared& sh)
 {
-    __shared__ uint32_t sBuckets[kSplatWordsPerGroup * 32];
-    __shared__ int4 sBlocks[kSplatQueue];
-    __shared__ uint32_t sNumBuckets, sNumBlocks;
+    uint32_t (&sBuckets)[kSplatWordsPerGroup * 32] = sh.sBuckets;
+    int4 (&sBlocks)[kSplatQueue] = sh.sBlocks;
+    uint32_t& sNumBuckets = sh.sNumBuckets;
+    uint32_t& sNumBlocks = sh.sNumBlocks;
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
     const int tilesX = (int)((rp.m_width + 7) / 8), tilesY = (int)((rp.m_height + 7) / 8);
@@ -869,7 +880,7 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
     // voxel on top covers every rounding on the way (|p/vs| < 2^16 where the quotient is resolved to 2^-8).
     const float growLo = (rp.m_useGradients ? 1.75f : 1.25f) * vs, growHi = (rp.m_useGradients ? 0.75f : 0.25f) * vs;
 
-    if (blockIdx.x >= nSplatGroups) { // the extra workgroup (launched only with a schedule)
+    if (group >= nSplatGroups) { // the extra workgroup (launched only with a schedule)
         schedule_tiles(sched, feedback, (uint32_t)(tilesX * tilesY), phase, numCUs, sBuckets);
         return;
     }
@@ -877,7 +888,7 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
     __syncthreads();
     // 1: occupied buckets of this group's words
     if (threadIdx.x < kSplatWordsPerGroup) {
-        const uint32_t wordIdx = blockIdx.x * kSplatWordsPerGroup + threadIdx.x;
+        const uint32_t wordIdx = group * kSplatWordsPerGroup + threadIdx.x;
         uint32_t bits = wordIdx < nWords ? hd.d_bucketBits[wordIdx] : 0u;
         while (bits) {
             const uint32_t bucket = wordIdx * 32u + (uint32_t)(__ffs((int)bits) - 1);
@@ -958,6 +969,14 @@ __global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashPar
         if (threadIdx.x == 0) sNumBlocks = 0u;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_interval_splat(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp,
+                                                        VhRayCastParams rp, uint4* heads, int4* lists, uint32_t cap,
+                                                        uint32_t* sched, uint32_t phase, uint32_t numCUs, uint32_t nSplatGroups, uint32_t* feedback)
+{
+    __shared__ SplatShared sh;
+    interval_splat_group(hd, hp, cp, rp, heads, lists, cap, sched, phase, numCUs, nSplatGroups, feedback, blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void k_interval_clear(uint4* heads, uint32_t n)
@@ -1757,9 +1776,29 @@ struct CoCompactify {
     uint32_t firstGroup; // 0: nothing to co-launch
 };
 
+// The interval splat of the NEXT render, for the pose of the frame being integrated, behind the compactify groups.  It
+// lists the table as it stands before that frame's pass over the voxels: what the pass frees stays listed with
+// all-zero voxels (weight 0: read like an absent block), what the next alloc adds is not listed and is empty anyway.
+struct CoSplat {
+    VhRayCastParams rp; // view of the next render
+    VhDepthCameraParams cp;
+    uint4* heads;
+    int4* lists;
+    uint32_t* sched;
+    uint32_t* feedback;
+    uint32_t cap, phase, numCUs, nSplatGroups;
+    uint32_t firstGroup; // 0: nothing to co-launch
+};
+
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
-__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job)
+__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job, CoSplat splat)
 {
+    __shared__ SplatShared sh;
+    if (splat.firstGroup != 0u && blockIdx.x >= splat.firstGroup) {
+        interval_splat_group(job.hd, job.hp, splat.cp, splat.rp, splat.heads, splat.lists, splat.cap, splat.sched, splat.phase, splat.numCUs,
+                             splat.nSplatGroups, splat.feedback, blockIdx.x - splat.firstGroup, sh);
+        return;
+    }
     if (job.firstGroup != 0u && blockIdx.x >= job.firstGroup) {
         compactify_words(job.hd, job.hp, job.cp, (blockIdx.x - job.firstGroup) * blockDim.x + threadIdx.x);
         return;
@@ -3020,21 +3059,42 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
     return vh_last_launch_error();
 }
 
-int vh_compute_normals_co(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* fj, vhStream_t stream)
+int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* fj,
+                           const VhRayCastParams* nextView, uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
+                           uint32_t* d_schedule, uint32_t phase, uint32_t* d_longestList, vhStream_t stream)
 {
     if (!d_output4 || !d_input4) return VH_ERR_BAD_ARGUMENT;
     if (width * height == 0) return VH_OK;
     uint32_t groups = cdiv((uint64_t)width * height, 256);
     CoCompactify job;
     std::memset(&job, 0, sizeof(job));
+    CoSplat sp;
+    std::memset(&sp, 0, sizeof(sp));
     if (fj && fj->allocLaunched && !fj->compactifyLaunched && fj->hashData.d_hash) {
         job.hd = fj->hashData; job.hp = fj->hashParams; job.cp = fj->cp;
         job.firstGroup = groups;
         groups += cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, 256);
         fj->compactifyLaunched = 1;
+        if (nextView && d_tileHeads && nextView->m_width != 0 && nextView->m_height != 0) { // needs the job's table (job.hd / job.hp)
+            sp.rp = *nextView; sp.cp = fj->cp;
+            sp.heads = reinterpret_cast<uint4*>(d_tileHeads);
+            sp.lists = reinterpret_cast<int4*>(d_tileBlocks);
+            sp.sched = d_schedule; sp.feedback = d_longestList;
+            sp.cap = d_tileBlocks ? tileCapacity : 0u;
+            sp.phase = phase;
+            sp.numCUs = d_schedule ? device_num_cus() : 256u;
+            sp.nSplatGroups = cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, kSplatWordsPerGroup);
+            sp.firstGroup = groups;
+            groups += sp.nSplatGroups + (d_schedule ? 1u : 0u);
+        }
     }
-    k_compute_normals<<<groups, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job);
+    k_compute_normals<<<groups, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job, sp);
     return vh_last_launch_error();
+}
+
+int vh_compute_normals_co(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, VhFrameJob* fj, vhStream_t stream)
+{
+    return vh_compute_normals_co2(d_output4, d_input4, width, height, fj, nullptr, nullptr, nullptr, 0u, nullptr, 0u, nullptr, stream);
 }
 
 int vh_compute_normals(float* d_output4, const float* d_input4, uint32_t width, uint32_t height, vhStream_t stream)

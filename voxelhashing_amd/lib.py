@@ -56,6 +56,7 @@ PROTOTYPES = {
     "vh_compute_normals": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "vh_render_intervals_co": (C.c_int, [P(T.HashData), P(T.HashParams), P(T.RayCastData), P(T.DepthCameraParams), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, P(T.FrameJob), _VP]),
     "vh_compute_normals_co": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, P(T.FrameJob), _VP]),
+    "vh_compute_normals_co2": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, P(T.FrameJob), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP]),
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
     "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
     "vh_stream_in_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP]),

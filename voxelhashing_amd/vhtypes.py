@@ -218,6 +218,8 @@ class FrameJob(C.Structure):
         ("allocLaunched", C.c_uint8),
         ("compactifyLaunched", C.c_uint8),
         ("pad0", C.c_uint8 * 2),
+        ("frameNumber", C.c_uint32),
+        ("tableEpoch", C.c_uint32),
     ]
 
 
