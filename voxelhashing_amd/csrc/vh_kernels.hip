@@ -1748,8 +1748,11 @@ VHD bool co_alloc(const CoAlloc& job)
 
 // small tables: 5 waves per SIMD keep all tiles of a 640x480 frame resident at once (4800 waves <= 5 x 4 x 256): the
 // march is a latency chain, and a second round of waves costs as much as the first
+#ifndef VH_RENDER_WAVES
+#define VH_RENDER_WAVES 5
+#endif
 template <bool GRADIENTS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VH_RENDER_WAVES, VH_RENDER_WAVES)))
 void k_render(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCameraParams cp, VhRayCastParams rp,
               uint4* heads, const int4* lists, uint32_t cap, uint32_t* sched, uint32_t phase, CoAlloc job)
 {

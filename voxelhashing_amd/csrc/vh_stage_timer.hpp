@@ -23,7 +23,12 @@ struct VhStageTimer {
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        // timing only: device-scope release (a default event record makes the queue write back its caches and idles it
+        // for ~6 us, which distorts the frame rate being measured)
+        if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipEventCreate(&e);
+        }
         return e;
     }
     void start(int stage, hipStream_t s)
