@@ -55,6 +55,9 @@ def parse_args(argv=None):
     p.add_argument("--event-stride", type=int, default=0, help="HIP events around k_render on every n-th timed frame (0: steps/10, at most 8)")
     p.add_argument("--no-alloc-ahead", action="store_true", help="alloc + compactify on the main stream, behind the ray cast")
     p.add_argument("--no-streaming", action="store_true", help="cfg3 without its per-frame stream out / stream in")
+    p.add_argument("--streaming-radius", type=float, default=0.0, help="cfg3: radius of the streaming sphere in metres (0: the reference's formula, DepthSensing.cpp:1340-1355 -- with scene S1 nothing ever leaves it)")
+    p.add_argument("--streaming-pos-z", type=float, default=0.0, help="cfg3: centre of the streaming sphere in front of the camera (0: the reference's formula)")
+    p.add_argument("--streaming-extent", type=float, default=0.0, help="cfg3: edge of a streaming chunk in metres (0: 1 m, zParametersDefault.txt)")
     p.add_argument("--frames-in-flight", type=int, default=16, help="frames the host may run ahead of the device (0: no bound)")
     p.add_argument("--preroll-seconds", type=float, default=0.3, help="untimed device pre-roll before the warm-up (clocks, code objects)")
     p.add_argument("--no-extra-legs", action="store_true", help="skip the dense-scene integrate leg, the host-fed leg and cfg1")
@@ -186,6 +189,8 @@ class GpuWorkload:
         self.cfg = cfg
         self.cfg_name = cfg_name
         self.hp, self.cp, self.rp = synth.config_params(cfg)
+        if args.streaming_extent > 0:
+            self.hp.m_streamingVoxelExtents[:] = [args.streaming_extent] * 3
         self.streaming = bool(cfg.get("streaming")) and not args.no_streaming if streaming is None else streaming
         # stage timers (HIP events around every stage) are switched on for a slice of the warm-up only;
         # the timed region records events around the dominant kernel (raycast) alone
@@ -232,6 +237,11 @@ class GpuWorkload:
             mn = [self.hp.m_streamingMinGridPos[i] for i in range(3)]
             self.grid = E.CUDASceneRepChunkGrid(self.scene, ext, dims, mn, self.hp.m_streamingInitialChunkListSize, True, self.opt.s_streamingOutParts)
             pos, rad = synth.streaming_sphere(self.hp, self.cp)
+            if args.streaming_radius > 0:
+                rad = args.streaming_radius
+            if args.streaming_pos_z > 0:
+                pos = np.array([0.0, 0.0, args.streaming_pos_z], dtype=np.float32)
+            self.streaming_sphere = (float(pos[2]), float(rad), float(ext[0]))
             ropt.update(s_streamingEnabled=1, s_streamingPos=pos, s_streamingRadius=rad)
         self.recon = E.Reconstruction(self.scene, self.ray, self.grid, self.cp, E.Reconstruction.defaultOptions(**ropt))
         self.python_loop = bool(args.python_loop)
@@ -547,7 +557,8 @@ def main(argv=None):
             "rooflines": rooflines,
         }
         if wl.streaming:
-            result["streaming"] = dict(blocks_out=int(st1["blocksStreamedOut"] - st0["blocksStreamedOut"]),
+            result["streaming"] = dict(sphere_centre_z=wl.streaming_sphere[0], sphere_radius=wl.streaming_sphere[1], chunk_extent=wl.streaming_sphere[2],
+                                       parts=int(wl.opt.s_streamingOutParts), worker_thread=True, blocks_out=int(st1["blocksStreamedOut"] - st0["blocksStreamedOut"]),
                                        blocks_in=int(st1["blocksStreamedIn"] - st0["blocksStreamedIn"]),
                                        blocks_per_second=round((st1["blocksStreamedOut"] - st0["blocksStreamedOut"] + st1["blocksStreamedIn"] - st0["blocksStreamedIn"]) / elapsed, 1))
     wl.close()

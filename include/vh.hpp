@@ -259,6 +259,8 @@ public:
     void streamInToGPUPass0CPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded = true);
     void streamInToGPUPass1GPU(bool multiThreaded = true);
     unsigned int integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts);
+    // blocks that stream-in passes could not insert and that went back to the host grid (not in the reference)
+    unsigned int getNumFailedInserts() const { return m_numFailedInserts; }
 
     void debugCheckForDuplicates() const; // .cpp:313-341; throws vh::Error
     void startMultiThreading();           // .h:248
@@ -318,6 +320,8 @@ private:
     void destroy();
     void setBit(unsigned int index);
     void resetBit(unsigned int index);
+    void takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev);
+    unsigned int m_numFailedInserts;
 
     unsigned int m_maxNumberOfSDFBlocksIntegrateFromGlobalHash;
 
@@ -331,6 +335,7 @@ private:
     vh::SDFBlock* d_SDFBlockOutput;
     vh::SDFBlock* d_SDFBlockInput;
     unsigned int* d_SDFBlockCounter;
+    unsigned int* d_insertFailed; // {count, indices ...} of the blocks a stream-in pass could not insert
     unsigned int* d_bitMask;
     void* m_copyStream; // hipStream_t of the worker thread
     int m_device;       // HIP device the scene lives on (the worker thread binds to it)

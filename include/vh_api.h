@@ -174,6 +174,11 @@ int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSD
 /* chunkToGlobalHashPass1CUDA(params, hashData, n, heapCountPrev, descs, blocks)           :162 */
 int vh_stream_in_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
                        const VhSDFBlockDesc* d_descs, int32_t lockToken, vhStream_t stream);
+/* the same, reporting which blocks could not be inserted (their bucket and its list were full, or two blocks of the
+ * pass overflowed one bucket): d_failed[0], zeroed by the caller, counts them, d_failed[1 ..] lists their indices into
+ * d_descs (room for n).  The reference has no such case handling (its overflow branch is an unported remnant). */
+int vh_stream_in_pass1_report(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                              const VhSDFBlockDesc* d_descs, int32_t lockToken, uint32_t* d_failed, vhStream_t stream);
 /* chunkToGlobalHashPass2CUDA(params, hashData, n, heapCountPrev, descs, blocks)           :192 */
 int vh_stream_in_pass2(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
                        const VhSDFBlockDesc* d_descs, const VhVoxel* d_blocks, vhStream_t stream);
@@ -289,6 +294,9 @@ int vh_chunk_grid_reset(VhChunkGrid* g);
 int vh_chunk_grid_debug_check_for_duplicates(VhChunkGrid* g);
 /* host-side statistics: {chunks allocated, blocks on the host, bits set} */
 int vh_chunk_grid_get_statistics(VhChunkGrid* g, uint32_t out[3]);
+/* blocks that stream-in passes could not insert (bucket and list full, or a second overflow of one bucket in a pass) and
+ * that went back to the host grid for a later pass; not in the reference, which has no defined behaviour there */
+int vh_chunk_grid_get_num_failed_inserts(VhChunkGrid* g, uint32_t* out);
 /* copies the host chunk grid content: descs[n], blocks[n*512] (pass NULL to query n) */
 int vh_chunk_grid_download_host_blocks(VhChunkGrid* g, VhSDFBlockDesc* descs, VhVoxel* blocks, uint32_t capacity, uint32_t* n);
 /* saveToFile / loadFromFile (.hashgrid v1) DSC/CUDASceneRepChunkGrid.h:459-548 */

@@ -47,6 +47,8 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(VhHashEntry), sizeof(VhVoxel), sizeof(VhHashParams),
          sizeof(VhDepthCameraParams), sizeof(VhRayCastParams), sizeof(VhHashData), sizeof(VhDepthCameraData),
          sizeof(VhRayCastData), sizeof(VhSDFBlockDesc), sizeof(VhSceneOptions));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(VhFrameJob), sizeof(VhReconstructionOptions), sizeof(VhSequenceFrame), sizeof(VhReconstructionStats),
+         offsetof(VhFrameJob, lockToken), offsetof(VhReconstructionOptions, s_streamingRadius), offsetof(VhSequenceFrame, color));
   printf("%zu %zu %zu %zu %zu\n", offsetof(VhHashParams, m_hashNumBuckets), offsetof(VhHashParams, m_virtualVoxelSize),
          offsetof(VhHashParams, m_streamingVoxelExtents), offsetof(VhRayCastParams, m_width), offsetof(VhHashData, d_bucketCount));
   return 0; }
@@ -62,6 +64,10 @@ int main(void) {
                                   T.DepthCameraData, T.RayCastData, T.SDFBlockDesc, T.SceneOptions)]
     assert sizes == want
     assert sizes[:5] == [32, 8, 224, 32, 304]  # reference layouts
+    loop = [int(v) for v in out[1].split()]
+    assert loop == [C.sizeof(T.FrameJob), C.sizeof(T.ReconstructionOptions), C.sizeof(T.SequenceFrame), C.sizeof(T.ReconstructionStats),
+                    T.FrameJob.lockToken.offset, T.ReconstructionOptions.s_streamingRadius.offset, T.SequenceFrame.color.offset]
+    out = [out[0]] + out[2:]
     offs = [int(v) for v in out[1].split()]
     assert offs == [T.HashParams.m_hashNumBuckets.offset, T.HashParams.m_virtualVoxelSize.offset,
                     T.HashParams.m_streamingVoxelExtents.offset, T.RayCastParams.m_width.offset, T.HashData.d_bucketCount.offset]

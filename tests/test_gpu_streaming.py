@@ -134,3 +134,46 @@ def test_worker_thread_protocol_smoke(vh, oracle_lib):
     s = gs.state(with_voxels=False)
     assert s["num_occupied"] > 10
     assert gs.debugHash()["duplicates"] == 0
+
+
+def test_per_frame_streaming_at_cfg3_size_keeps_every_invariant(vh):
+    """BASELINE.json configs[2] as DepthSensing.cpp:881-903 runs it: cfg3's tables (20 M entries, 1 cm voxels, 640x480),
+    80 parts, the worker thread on, streamOutToCPUPass0GPU / streamInToGPUPass1GPU / integrate(..., getBitMaskGPU()) every
+    frame, through the native frame loop, 120 frames of the orbit.  (With the reference's own sphere -- radius 3.9 m --
+    nothing of scene S1 ever leaves; here the sphere is 1.2 m around a point 1.6 m in front of the camera and the chunks
+    are 0.5 m, so blocks leave and come back all the time.)  Size-independent properties: no block is in the table and in
+    the host grid at once (debugCheckForDuplicates), heap and table partition the block pool and every free block is zero
+    (canonical.check_invariants via state()), the occupancy summary is in step with the table, no status word is raised."""
+    from voxelhashing_amd import engine as E
+    c = dict(synth.CONFIGS["cfg3"])
+    c.update(num_sdf_blocks=1 << 16)  # the table at full size; the voxel pool sized to be downloadable
+    hp, cp, rp = synth.config_params(c)
+    hp.m_streamingVoxelExtents[:] = EXT
+    hp.m_streamingGridDimensions[:] = DIMS
+    hp.m_streamingMinGridPos[:] = MINP
+    opt = T.make_scene_options(offline=False, gc=True, starve=15, streaming_out_parts=80)
+    scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+    grid = E.CUDASceneRepChunkGrid(scene, EXT, DIMS, MINP, 2000, True, 80)
+    n = 120
+    poses = [synth.orbit_pose(k, 240) for k in range(n)]
+    frames = [E.synth_frame(synth.S1_SPHERES, 0, p, cp) for p in poses]
+    recon = E.Reconstruction(scene, ray, grid, cp, E.Reconstruction.defaultOptions(s_streamingEnabled=1, s_streamingPos=STREAM_POS[:3], s_streamingRadius=RADIUS,
+                                                                                  s_maxFramesInFlight=8))
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+    for k0 in range(0, n, 40):
+        recon.run(seq, k0, 40)
+        recon.synchronize()
+        grid.debugCheckForDuplicates()
+        st = scene.getState()
+        assert st[T.STATE_HEAP_UNDERFLOW] == 0 and st[T.STATE_INSERT_FAILED] == 0
+    stats = recon.getStats()
+    assert stats["frames"] == n
+    assert stats["blocksStreamedOut"] > 100 and stats["blocksStreamedIn"] > 10, stats  # (one chunk per frame comes back at most)
+    grid.reset()  # stops the worker (the host grid is dropped), so that the table can be read in peace
+    s = scene.state()  # invariants + occupancy summary
+    assert s["num_occupied"] > 500
+    assert scene.debugHash()["duplicates"] == 0
+    hits = (ray.download()["depth"] != -np.inf).sum()
+    assert hits > 20000
+    recon.close()
+    grid.close()

@@ -254,6 +254,12 @@ int vh_chunk_grid_debug_check_for_duplicates(VhChunkGrid* g)
     if (!g) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { g->impl.debugCheckForDuplicates(); });
 }
+int vh_chunk_grid_get_num_failed_inserts(VhChunkGrid* g, uint32_t* out)
+{
+    if (!g || !out) return VH_ERR_BAD_ARGUMENT;
+    *out = g->impl.getNumFailedInserts();
+    return VH_OK;
+}
 int vh_chunk_grid_get_statistics(VhChunkGrid* g, uint32_t out[3])
 {
     if (!g || !out) return VH_ERR_BAD_ARGUMENT;

@@ -72,13 +72,14 @@ CUDASceneRepChunkGrid::CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSD
 {
     m_sceneRepHashSDF = sceneRepHashSDF;
     m_currentPart = 0;
+    m_numFailedInserts = 0;
     m_streamOutParts = streamOutParts ? streamOutParts : 1;
     m_maxNumberOfSDFBlocksIntegrateFromGlobalHash = 100000; // DSC/CUDASceneRepChunkGrid.h:162
     h_SDFBlockDescOutput = nullptr; h_SDFBlockOutput = nullptr;
     h_SDFBlockDescInput = nullptr; h_SDFBlockInput = nullptr; h_counter = nullptr;
     d_SDFBlockDescOutput = nullptr; d_SDFBlockDescInput = nullptr;
     d_SDFBlockOutput = nullptr; d_SDFBlockInput = nullptr;
-    d_SDFBlockCounter = nullptr; d_bitMask = nullptr; m_copyStream = nullptr;
+    d_SDFBlockCounter = nullptr; d_insertFailed = nullptr; d_bitMask = nullptr; m_copyStream = nullptr;
     s_terminateThread = true; // by default the thread is disabled
     s_nStreamdInBlocks = 0; s_nStreamdOutBlocks = 0;
     s_posCamera = { 0.0f, 0.0f, 0.0f };
@@ -113,6 +114,7 @@ void CUDASceneRepChunkGrid::create(const vh::vec3f& voxelExtends, const vh::vec3
     checkHip(hipMalloc((void**)&d_SDFBlockOutput, sizeof(vh::SDFBlock) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockInput, sizeof(vh::SDFBlock) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockCounter, sizeof(unsigned int)), "hipMalloc");
+    checkHip(hipMalloc((void**)&d_insertFailed, sizeof(unsigned int) * (1 + (size_t)m_maxNumberOfSDFBlocksIntegrateFromGlobalHash)), "hipMalloc");
     checkHip(hipMalloc((void**)&d_bitMask, sizeof(unsigned int) * m_bitMask.size()), "hipMalloc");
     checkHip(hipGetDevice(&m_device), "hipGetDevice"); // one instance is bound to one device
     hipStream_t cs;
@@ -132,7 +134,7 @@ void CUDASceneRepChunkGrid::destroy()
     (void)hipHostFree(h_SDFBlockDescInput); (void)hipHostFree(h_SDFBlockInput); (void)hipHostFree(h_counter);
     (void)hipFree(d_SDFBlockDescOutput); (void)hipFree(d_SDFBlockDescInput);
     (void)hipFree(d_SDFBlockOutput); (void)hipFree(d_SDFBlockInput);
-    (void)hipFree(d_SDFBlockCounter); (void)hipFree(d_bitMask);
+    (void)hipFree(d_SDFBlockCounter); (void)hipFree(d_insertFailed); (void)hipFree(d_bitMask);
 }
 
 // ---------------------------------------------------------------------------
@@ -374,6 +376,8 @@ void CUDASceneRepChunkGrid::streamOutToCPU(const vh::vec3f& posCamera, float rad
 void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded)
 {
     std::unique_lock<std::mutex> lock(hMutexOut, std::defer_lock);
+    if (multiThreaded && s_terminateThread)
+        throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamOutToCPUPass0GPU(multiThreaded): the streaming thread is not running");
     if (multiThreaded) {
         hEventOutProduce.wait();
         lock.lock();
@@ -520,6 +524,10 @@ void CUDASceneRepChunkGrid::streamInToGPUPass0CPU(const vh::vec3f& posCamera, fl
 void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
 {
     std::unique_lock<std::mutex> lock(hMutexIn, std::defer_lock);
+    // the worker prepares stream-in passes only in online mode (workerLoop; DSC/CUDASceneRepChunkGrid.cpp:13): waiting
+    // for it in offline mode, or while it is stopped, would never end
+    if (multiThreaded && (s_terminateThread || m_sceneRepHashSDF->getOptions().s_offlineProcessing))
+        throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamInToGPUPass1GPU(multiThreaded): no worker thread prepares the pass (offline processing, or streaming thread stopped)");
     if (multiThreaded) {
         hEventInConsume.wait();
         lock.lock();
@@ -536,14 +544,47 @@ void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
         }
         const int32_t token = m_sceneRepHashSDF->nextLockToken();
         m_sceneRepHashSDF->noteTableEdited();
-        check(vh_stream_in_pass1(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, token, stream), "chunkToGlobalHashPass1CUDA");
+        hipStream_t hs = (hipStream_t)stream;
+        checkHip(hipMemsetAsync(d_insertFailed, 0, sizeof(unsigned int), hs), "clear failed inserts");
+        check(vh_stream_in_pass1_report(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, token, d_insertFailed, stream), "chunkToGlobalHashPass1CUDA");
         check(vh_stream_in_pass2(&hd, &hp, s_nStreamdInBlocks, heapCountPrev, d_SDFBlockDescInput, (const VhVoxel*)d_SDFBlockInput, stream), "chunkToGlobalHashPass2CUDA");
         // update heap counter (pinned source: stays valid until the copy ran)
         h_counter[0] = heapCountPrev - s_nStreamdInBlocks;
-        checkHip(hipMemcpyAsync(hd.d_heapCounter, &h_counter[0], sizeof(unsigned int), hipMemcpyHostToDevice, (hipStream_t)stream), "heapCounter");
-        checkHip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+        checkHip(hipMemcpyAsync(hd.d_heapCounter, &h_counter[0], sizeof(unsigned int), hipMemcpyHostToDevice, hs), "heapCounter");
+        checkHip(hipMemcpyAsync(&h_counter[1], d_insertFailed, sizeof(unsigned int), hipMemcpyDeviceToHost, hs), "failed inserts");
+        checkHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
+        if (h_counter[1] != 0) takeBackFailedInserts(h_counter[1], heapCountPrev);
     }
     if (multiThreaded) hEventInProduce.set();
+}
+
+// Blocks of the last stream-in pass that found no slot (their bucket and its list full, or a second overflow of one
+// bucket within the pass): the reference has no defined behaviour for them (DSC/VoxelUtilHashSDF.h:682-713).  Here they
+// go back to where they came from -- the host chunk grid -- and their SDF blocks back to the heap, cleared, so that no
+// block is lost and the pool still is the union of heap and table.  They come in again with a later pass.
+void CUDASceneRepChunkGrid::takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev)
+{
+    HashData& hd = m_sceneRepHashSDF->getHashData();
+    hipStream_t hs = (hipStream_t)m_sceneRepHashSDF->getStream();
+    std::vector<unsigned int> idx(nFailed), blockIds(nFailed);
+    checkHip(hipMemcpy(idx.data(), d_insertFailed + 1, sizeof(unsigned int) * nFailed, hipMemcpyDeviceToHost), "failed insert list");
+    unsigned int counter = 0;
+    checkHip(hipMemcpy(&counter, hd.d_heapCounter, sizeof(unsigned int), hipMemcpyDeviceToHost), "heapCounter");
+    for (unsigned int k = 0; k < nFailed; k++) {
+        const unsigned int i = idx[k];
+        if (i >= s_nStreamdInBlocks) throw vh::Error(VH_ERR_INSERT_FAILED, "stream-in: corrupt list of failed inserts");
+        // the heap slot the pass took for this block (chunkToGlobalHashPass1Kernel: heap[heapCountPrev - i])
+        checkHip(hipMemcpy(&blockIds[k], hd.d_heap + (heapCountPrev - i), sizeof(unsigned int), hipMemcpyDeviceToHost), "heap slot");
+        checkHip(hipMemsetAsync(hd.d_SDFBlocks + (size_t)blockIds[k] * VH_SDF_BLOCK_VOXELS, 0, sizeof(vh::SDFBlock), hs), "clear block");
+        integrateInChunkGrid(&h_SDFBlockDescInput[i], &h_SDFBlockInput[i], 1); // the staging copy is still there
+    }
+    // appendHeap, DSC/VoxelUtilHashSDF.h:525-529, nFailed times
+    checkHip(hipMemcpyAsync(hd.d_heap + counter + 1, blockIds.data(), sizeof(unsigned int) * nFailed, hipMemcpyHostToDevice, hs), "heap");
+    counter += nFailed;
+    checkHip(hipMemcpyAsync(hd.d_heapCounter, &counter, sizeof(unsigned int), hipMemcpyHostToDevice, hs), "heapCounter");
+    checkHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
+    s_nStreamdInBlocks -= nFailed;
+    m_numFailedInserts += nFailed;
 }
 
 // DSC/CUDASceneRepChunkGrid.cpp:268-311
@@ -637,6 +678,10 @@ void CUDASceneRepChunkGrid::saveToFile(const std::string& filename, const vh::ve
 {
     const bool wasRunning = !s_terminateThread;
     stopMultiThreading();
+    struct Restart {
+        CUDASceneRepChunkGrid* g; bool on;
+        ~Restart() { if (on) g->startMultiThreading(); }
+    } restart{ this, wasRunning };
     streamOutToCPUAll();
 
     FILE* f = std::fopen(filename.c_str(), "wb");
@@ -666,7 +711,6 @@ void CUDASceneRepChunkGrid::saveToFile(const std::string& filename, const vh::ve
 
     unsigned int nStreamedBlocks;
     streamInToGPUAll(camPos, radius, true, nStreamedBlocks);
-    if (wasRunning) startMultiThreading();
 }
 
 void CUDASceneRepChunkGrid::loadFromFile(const std::string& filename, const vh::vec3f& camPos, float radius)
@@ -674,6 +718,11 @@ void CUDASceneRepChunkGrid::loadFromFile(const std::string& filename, const vh::
     (void)camPos; (void)radius;
     const bool wasRunning = !s_terminateThread;
     stopMultiThreading();
+    // whatever happens below, the worker thread runs again afterwards if it ran before
+    struct Restart {
+        CUDASceneRepChunkGrid* g; bool on;
+        ~Restart() { if (on) g->startMultiThreading(); }
+    } restart{ this, wasRunning };
     streamOutToCPUAll();
     clearGrid();
     {
@@ -685,6 +734,15 @@ void CUDASceneRepChunkGrid::loadFromFile(const std::string& filename, const vh::
     FILE* f = std::fopen(filename.c_str(), "rb");
     if (!f) throw vh::Error(VH_ERR_IO, "cannot open " + filename);
     struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{ f };
+    // no count in the file is trusted beyond what the file can hold
+    if (std::fseek(f, 0, SEEK_END) != 0) throw vh::Error(VH_ERR_IO, "cannot seek in " + filename);
+    const long fileSizeL = std::ftell(f);
+    if (fileSizeL < 0 || std::fseek(f, 0, SEEK_SET) != 0) throw vh::Error(VH_ERR_IO, "cannot seek in " + filename);
+    const uint64_t fileSize = (uint64_t)fileSizeL;
+    auto remaining = [&]() -> uint64_t {
+        const long at = std::ftell(f);
+        return (at < 0 || (uint64_t)at > fileSize) ? 0u : fileSize - (uint64_t)at;
+    };
 
     unsigned int version = 0, listSize = 0, numOccupiedChunks = 0;
     float voxelSize = 0.0f;
@@ -704,22 +762,32 @@ void CUDASceneRepChunkGrid::loadFromFile(const std::string& filename, const vh::
     {
         std::lock_guard<std::mutex> l(m_gridMutex);
         const size_t nChunks = (size_t)m_gridDimensions.x * m_gridDimensions.y * m_gridDimensions.z;
-        for (unsigned int i = 0; i < numOccupiedChunks; i++) {
-            unsigned int index = 0;
-            uint64_t nb = 0, nd = 0;
-            if (!rd(f, index) || index >= nChunks) throw vh::Error(VH_ERR_IO, "invalid chunk index");
-            std::unique_ptr<ChunkDesc> c(new ChunkDesc(m_initialChunkDescListSize));
-            if (!rd(f, nb)) throw vh::Error(VH_ERR_IO, "invalid read");
-            c->getSDFBlocks().resize(nb);
-            if (nb && std::fread(c->getSDFBlocks().data(), sizeof(vh::SDFBlock), nb, f) != nb) throw vh::Error(VH_ERR_IO, "invalid read");
-            if (!rd(f, nd)) throw vh::Error(VH_ERR_IO, "invalid read");
-            c->getSDFBlockDescs().resize(nd);
-            if (nd && std::fread(c->getSDFBlockDescs().data(), sizeof(SDFBlockDesc), nd, f) != nd) throw vh::Error(VH_ERR_IO, "invalid read");
-            // the reference leaves the bit mask cleared after a load (alloc may then re-create blocks
-            // of streamed-out chunks); here the mask follows the grid content
-            if (c->isStreamedOut()) setBit(index);
-            m_grid[index] = std::move(c);
+        try {
+            for (unsigned int i = 0; i < numOccupiedChunks; i++) {
+                unsigned int index = 0;
+                uint64_t nb = 0, nd = 0;
+                if (!rd(f, index) || index >= nChunks) throw vh::Error(VH_ERR_IO, "invalid chunk index");
+                if (m_grid.count(index)) throw vh::Error(VH_ERR_IO, "chunk listed twice");
+                std::unique_ptr<ChunkDesc> c(new ChunkDesc(m_initialChunkDescListSize));
+                if (!rd(f, nb) || nb > remaining() / sizeof(vh::SDFBlock)) throw vh::Error(VH_ERR_IO, "invalid read: more blocks than the file holds");
+                c->getSDFBlocks().resize(nb);
+                if (nb && std::fread(c->getSDFBlocks().data(), sizeof(vh::SDFBlock), nb, f) != nb) throw vh::Error(VH_ERR_IO, "invalid read");
+                if (!rd(f, nd) || nd > remaining() / sizeof(SDFBlockDesc)) throw vh::Error(VH_ERR_IO, "invalid read: more descriptors than the file holds");
+                // the two vectors of a chunk are parallel (ChunkDesc::addSDFBlock pushes to both): everything
+                // downstream copies nb descriptors
+                if (nd != nb) throw vh::Error(VH_ERR_IO, "invalid chunk: " + std::to_string(nb) + " blocks but " + std::to_string(nd) + " descriptors");
+                c->getSDFBlockDescs().resize(nd);
+                if (nd && std::fread(c->getSDFBlockDescs().data(), sizeof(SDFBlockDesc), nd, f) != nd) throw vh::Error(VH_ERR_IO, "invalid read");
+                // the reference leaves the bit mask cleared after a load (alloc may then re-create blocks
+                // of streamed-out chunks); here the mask follows the grid content
+                if (c->isStreamedOut()) setBit(index);
+                m_grid[index] = std::move(c);
+            }
+        } catch (...) { // a refused file leaves an empty grid, not half of one
+            m_grid.clear();
+            std::fill(m_bitMask.begin(), m_bitMask.end(), 0u);
+            m_bitMaskDirty = true;
+            throw;
         }
     }
-    if (wasRunning) startMultiThreading();
 }

@@ -2683,14 +2683,17 @@ __global__ __launch_bounds__(256) void k_stream_out_pass2(VhHashData hd, const V
 
 // chunkToGlobalHashPass1Kernel :143-160
 __global__ __launch_bounds__(64) void k_stream_in_pass1(VhHashData hd, VhHashParams hp, uint32_t n, uint32_t heapCountPrev,
-                                                        const VhSDFBlockDesc* descs, int32_t lockToken)
+                                                        const VhSDFBlockDesc* descs, int32_t lockToken, uint32_t* failed)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t ptr = hd.d_heap[heapCountPrev - i] * VH_SDF_BLOCK_VOXELS;
     const VhSDFBlockDesc dsc = descs[i];
-    if (!insert_hash_entry(hd, hp, mki3(dsc.pos[0], dsc.pos[1], dsc.pos[2]), (int)ptr, lockToken))
+    if (!insert_hash_entry(hd, hp, mki3(dsc.pos[0], dsc.pos[1], dsc.pos[2]), (int)ptr, lockToken)) {
         atomicAdd(&hd.d_state[VH_STATE_INSERT_FAILED], 1u);
+        // which ones: failed[0] counts them, failed[1 ...] lists their indices (the caller takes them back)
+        if (failed) failed[1u + atomicAdd(&failed[0], 1u)] = i;
+    }
 }
 
 // chunkToGlobalHashPass2Kernel :181-189
@@ -3300,14 +3303,21 @@ int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSD
     return vh_last_launch_error();
 }
 
-int vh_stream_in_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
-                       const VhSDFBlockDesc* d_descs, int32_t lockToken, vhStream_t stream)
+int vh_stream_in_pass1_report(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                              const VhSDFBlockDesc* d_descs, int32_t lockToken, uint32_t* d_failed, vhStream_t stream)
 {
     if (!hd || !hp || !d_descs) return VH_ERR_BAD_ARGUMENT;
     if (n == 0) return VH_OK;
     if (n > heapCountPrev + 1u) return VH_ERR_HEAP_EXHAUSTED;
-    k_stream_in_pass1<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(*hd, *hp, n, heapCountPrev, d_descs, lockToken);
+    if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
+    k_stream_in_pass1<<<cdiv(n, 64), 64, 0, (hipStream_t)stream>>>(*hd, *hp, n, heapCountPrev, d_descs, lockToken, d_failed);
     return vh_last_launch_error();
+}
+
+int vh_stream_in_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
+                       const VhSDFBlockDesc* d_descs, int32_t lockToken, vhStream_t stream)
+{
+    return vh_stream_in_pass1_report(hd, hp, n, heapCountPrev, d_descs, lockToken, nullptr, stream);
 }
 
 int vh_stream_in_pass2(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,

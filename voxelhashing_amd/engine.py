@@ -328,6 +328,11 @@ class CUDASceneRepChunkGrid:
         check(self.L.vh_chunk_grid_get_statistics(self.handle, out), "getStatistics")
         return dict(chunks=out[0], blocks=out[1], bits=out[2])
 
+    def getNumFailedInserts(self):
+        out = C.c_uint32(0)
+        check(self.L.vh_chunk_grid_get_num_failed_inserts(self.handle, C.byref(out)), "getNumFailedInserts")
+        return out.value
+
     def downloadHostBlocks(self):
         n = C.c_uint32()
         check(self.L.vh_chunk_grid_download_host_blocks(self.handle, None, None, 0, C.byref(n)), "downloadHostBlocks")

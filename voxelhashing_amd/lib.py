@@ -60,6 +60,7 @@ PROTOTYPES = {
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
     "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
     "vh_stream_in_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP]),
+    "vh_stream_in_pass1_report": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP, _VP]),
     "vh_stream_in_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, _VP, _VP]),
     "vh_synth_frame": (C.c_int, [_VP, C.c_int, C.c_int, _F16, P(T.DepthCameraParams), _VP, _VP, _VP]),
     "vh_debug_hash_ops": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
@@ -183,6 +184,7 @@ PROTOTYPES = {
     "vh_chunk_grid_reset": (C.c_int, [_VP]),
     "vh_chunk_grid_debug_check_for_duplicates": (C.c_int, [_VP]),
     "vh_chunk_grid_get_statistics": (C.c_int, [_VP, P(C.c_uint32)]),
+    "vh_chunk_grid_get_num_failed_inserts": (C.c_int, [_VP, P(C.c_uint32)]),
     "vh_chunk_grid_download_host_blocks": (C.c_int, [_VP, _VP, _VP, C.c_uint32, P(C.c_uint32)]),
     "vh_chunk_grid_save_to_file": (C.c_int, [_VP, C.c_char_p, _F16, C.c_float]),
     "vh_chunk_grid_load_from_file": (C.c_int, [_VP, C.c_char_p, _F16, C.c_float]),
