@@ -1772,16 +1772,18 @@ void k_render_large(VhHashData hd, VhHashParams hp, VhRayCastData rd, VhDepthCam
     render_tile<GRADIENTS, VH_TILE_LIST_CAPACITY_LARGE>(hd, hp, rd, cp, rp, heads, lists, cap, sched, phase, tileTab);
 }
 
+// Riders of computeNormals' launch.  They come FIRST in the grid (the schedule workgroup, the splat, the compactify
+// pass, then the image): each of them is a chain of dependent trips to memory, and what starts first ends first.
 struct CoCompactify {
     VhHashData hd;
     VhHashParams hp;
     VhDepthCameraParams cp;
-    uint32_t firstGroup; // 0: nothing to co-launch
+    uint32_t groups; // 0: nothing to co-launch
 };
 
-// The interval splat of the NEXT render, for the pose of the frame being integrated, behind the compactify groups.  It
-// lists the table as it stands before that frame's pass over the voxels: what the pass frees stays listed with
-// all-zero voxels (weight 0: read like an absent block), what the next alloc adds is not listed and is empty anyway.
+// The interval splat of the NEXT render, for the pose of the frame being integrated.  It lists the table as it stands
+// before that frame's pass over the voxels: what the pass frees stays listed with all-zero voxels (weight 0: read
+// like an absent block), what the next alloc adds is not listed and is empty anyway.
 struct CoSplat {
     VhRayCastParams rp; // view of the next render
     VhDepthCameraParams cp;
@@ -1790,23 +1792,29 @@ struct CoSplat {
     uint32_t* sched;
     uint32_t* feedback;
     uint32_t cap, phase, numCUs, nSplatGroups;
-    uint32_t firstGroup; // 0: nothing to co-launch
+    uint32_t groups; // nSplatGroups (+ 1 with a schedule); 0: nothing to co-launch
 };
 
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
 __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job, CoSplat splat)
 {
     __shared__ SplatShared sh;
-    if (splat.firstGroup != 0u && blockIdx.x >= splat.firstGroup) {
+    uint32_t g = blockIdx.x;
+    if (g < splat.groups) {
+        // the schedule workgroup first (one workgroup sorts all tiles: the longest chain), then the table's slices
+        const bool withSchedule = splat.groups > splat.nSplatGroups;
+        const uint32_t group = withSchedule ? (g == 0u ? splat.nSplatGroups : g - 1u) : g;
         interval_splat_group(job.hd, job.hp, splat.cp, splat.rp, splat.heads, splat.lists, splat.cap, splat.sched, splat.phase, splat.numCUs,
-                             splat.nSplatGroups, splat.feedback, blockIdx.x - splat.firstGroup, sh);
+                             splat.nSplatGroups, splat.feedback, group, sh);
         return;
     }
-    if (job.firstGroup != 0u && blockIdx.x >= job.firstGroup) {
-        compactify_words(job.hd, job.hp, job.cp, (blockIdx.x - job.firstGroup) * blockDim.x + threadIdx.x);
+    g -= splat.groups;
+    if (g < job.groups) {
+        compactify_words(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x);
         return;
     }
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    g -= job.groups;
+    const uint32_t idx = g * blockDim.x + threadIdx.x;
     if (idx >= width * height) return;
     const uint32_t x = idx % width, y = idx / width;
     const float mi = minf();
@@ -3078,8 +3086,8 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
     std::memset(&sp, 0, sizeof(sp));
     if (fj && fj->allocLaunched && !fj->compactifyLaunched && fj->hashData.d_hash) {
         job.hd = fj->hashData; job.hp = fj->hashParams; job.cp = fj->cp;
-        job.firstGroup = groups;
-        groups += cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, 256);
+        job.groups = cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, 256);
+        groups += job.groups;
         fj->compactifyLaunched = 1;
         if (nextView && d_tileHeads && nextView->m_width != 0 && nextView->m_height != 0) { // needs the job's table (job.hd / job.hp)
             sp.rp = *nextView; sp.cp = fj->cp;
@@ -3090,8 +3098,8 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
             sp.phase = phase;
             sp.numCUs = d_schedule ? device_num_cus() : 256u;
             sp.nSplatGroups = cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, kSplatWordsPerGroup);
-            sp.firstGroup = groups;
-            groups += sp.nSplatGroups + (d_schedule ? 1u : 0u);
+            sp.groups = sp.nSplatGroups + (d_schedule ? 1u : 0u);
+            groups += sp.groups;
         }
     }
     k_compute_normals<<<groups, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job, sp);
