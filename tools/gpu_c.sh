@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02p
+O=gpurun_out/r02q
 mkdir -p $O
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=$?; echo "pytest gpu rc=$rc" | tee -a $O/summary.txt
 tail -3 $O/pytest_gpu.log
@@ -15,7 +15,7 @@ timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/b
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extra-legs --preroll-seconds 0.05 > $O/trace.json 2> $O/trace.err; echo "trace rc=$?" | tee -a $O/summary.txt
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob("gpurun_out/r02p/bench_*.json")):
+for f in sorted(glob.glob("gpurun_out/r02q/bench_*.json")):
     try:
         j=json.loads([l for l in open(f) if l.startswith("{")][-1])
         print(f.split("/")[-1], j["value"], "us/frame", round(1e3*j["ms_per_step"],1), "host", j.get("host_enqueue_us_per_frame"), "render", j["roofline"]["avg_launch_us"], j["roofline"]["stage_us_warmup"])

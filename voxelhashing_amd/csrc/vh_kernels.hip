@@ -1717,8 +1717,6 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
 #undef VH_STAT_ARGS
 #undef VH_STAT_STORE
 
-// small tables: 5 waves per SIMD keep all tiles of a 640x480 frame resident at once (4800 waves <= 5 x 4 x 256): the
-// march is a latency chain, and a second round of waves costs as much as the first
 // Co-launch (CUDASceneRepHashSDF::integrateAhead): the workgroups behind the ray caster's own, `firstGroup` onwards,
 // run the alloc pass of the NEXT frame (four 8x8 pixel tiles each), and the workgroups behind computeNormals' own run
 // its compactify pass.  One launch instead of two streams: the extra workgroups are dispatched as the ray caster's
@@ -1746,10 +1744,12 @@ VHD bool co_alloc(const CoAlloc& job)
     return true;
 }
 
-// small tables: 5 waves per SIMD keep all tiles of a 640x480 frame resident at once (4800 waves <= 5 x 4 x 256): the
-// march is a latency chain, and a second round of waves costs as much as the first
+// small tables: all tiles of a 640x480 frame resident at once (4800 + 256 waves <= 6 x 4 x 256) -- the march is a
+// latency chain, and a second round of waves costs as much as the first -- and the riders behind them find free
+// slots sooner.  Six waves per SIMD (80 registers, 16 bytes of spill) measured against five (96): +1.5 % frames/s at
+// 640x480, +5 % at 1920x1080; four (128 registers): -9 %.
 #ifndef VH_RENDER_WAVES
-#define VH_RENDER_WAVES 5
+#define VH_RENDER_WAVES 6
 #endif
 template <bool GRADIENTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VH_RENDER_WAVES, VH_RENDER_WAVES)))
