@@ -58,6 +58,7 @@ def parse_args(argv=None):
     p.add_argument("--streaming-radius", type=float, default=0.0, help="cfg3: radius of the streaming sphere in metres (0: the reference's formula, DepthSensing.cpp:1340-1355 -- with scene S1 nothing ever leaves it)")
     p.add_argument("--streaming-pos-z", type=float, default=0.0, help="cfg3: centre of the streaming sphere in front of the camera (0: the reference's formula)")
     p.add_argument("--streaming-extent", type=float, default=0.0, help="cfg3: edge of a streaming chunk in metres (0: 1 m, zParametersDefault.txt)")
+    p.add_argument("--frames-on-host", action="store_true", help="the main workload is fed from pinned host memory (as the host-fed leg): its value is then the PCIe-inclusive rate, not the contract's")
     p.add_argument("--frames-in-flight", type=int, default=16, help="frames the host may run ahead of the device (0: no bound)")
     p.add_argument("--preroll-seconds", type=float, default=0.3, help="untimed device pre-roll before the warm-up (clocks, code objects)")
     p.add_argument("--no-extra-legs", action="store_true", help="skip the dense-scene integrate leg, the host-fed leg and cfg1")
@@ -463,7 +464,7 @@ def main(argv=None):
     dev = torch.device("cuda", local_rank)
 
     n_frames = args.warmup + args.steps
-    wl = GpuWorkload(args.config, n_frames, rank, args)
+    wl = GpuWorkload(args.config, n_frames, rank, args, frames_on_host=args.frames_on_host)
     # at least 8-10 pairs behind avg_launch_us, but not a pair around every launch: a record idles the queue for ~6 us
     stride = args.event_stride if args.event_stride > 0 else max(1, min(8, args.steps // 10))
     wl.set_event_stride(stride)
@@ -550,6 +551,7 @@ def main(argv=None):
                 "alloc_ahead": not args.no_alloc_ahead and not wl.streaming and not args.python_loop,
                 "frames_in_flight": args.frames_in_flight,
                 "preroll_frames": preroll_frames,
+                "frames_on_host": bool(args.frames_on_host),
             },
             "host_enqueue_us_per_frame": round(host_enqueue_us, 3),
             "host_wait_us_per_frame": round(host_wait_us, 3),

@@ -400,14 +400,15 @@ private:
     ReconstructionOptions m_opt;
     ReconstructionStats m_stats;
     unsigned int m_frameNumber;
-    // frames on the host: two staging slots fed by a copy stream
+    // frames on the host: a ring of staging slots fed by a copy stream
+    enum { kStagingSlots = 4 };
     void* m_copyStream;
-    float* d_stageDepth[2];
-    unsigned char* d_stageColorRaw[2];
-    float* d_stageColor[2];
-    void* m_slotReady[2]; // copy stream -> main stream
-    void* m_slotFree[2];  // main stream -> copy stream
-    bool m_slotUsed[2];
+    float* d_stageDepth[kStagingSlots];
+    unsigned char* d_stageColorRaw[kStagingSlots];
+    float* d_stageColor[kStagingSlots];
+    void* m_slotReady[kStagingSlots];             // copy stream -> main stream
+    unsigned int m_slotSceneFrame[kStagingSlots]; // the scene's frame count when the slot's frame was enqueued, + 1 (0: never used)
+    unsigned int m_uploads;                       // frames uploaded so far (the slot is m_uploads % kStagingSlots)
     std::vector<std::pair<void*, void*>> m_uploadTimers; // event pairs on the copy stream, not yet read
     std::vector<void*> m_timerPool;
 };

@@ -42,6 +42,10 @@ const char* vh_last_error_message(void);
 /* ---- device memory helpers (thin hipMalloc/hipMemcpy wrappers for FFI users) */
 int vh_malloc(void** devPtr, size_t bytes);
 int vh_free(void* devPtr);
+/* pinned, device-visible host memory (hipHostMalloc): what vh_upload_frame and the frame loop's host-fed mode read
+ * straight over the link */
+int vh_malloc_host(void** hostPtr, size_t bytes);
+int vh_free_host(void* hostPtr);
 int vh_memcpy_h2d(void* dst, const void* src, size_t bytes, vhStream_t stream);
 int vh_memcpy_d2h(void* dst, const void* src, size_t bytes, vhStream_t stream); /* synchronises the stream */
 int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream);

@@ -65,7 +65,20 @@ int vh_malloc(void** devPtr, size_t bytes)
 }
 int vh_free(void* devPtr)
 {
+    if (!devPtr) return VH_ERR_BAD_ARGUMENT;
     VH_HIP(hipFree(devPtr));
+    return VH_OK;
+}
+int vh_malloc_host(void** hostPtr, size_t bytes)
+{
+    if (!hostPtr) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipHostMalloc(hostPtr, bytes ? bytes : 1, hipHostMallocDefault));
+    return VH_OK;
+}
+int vh_free_host(void* hostPtr)
+{
+    if (!hostPtr) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipHostFree(hostPtr));
     return VH_OK;
 }
 int vh_memcpy_h2d(void* dst, const void* src, size_t bytes, vhStream_t stream)

@@ -2136,33 +2136,55 @@ __global__ __launch_bounds__(256) void k_convert_color_raw_to_float4(float4* out
 }
 
 // A sensor frame straight from (pinned, device-visible) host memory: the depth copied, the colour converted on the way
-// (convertColorRawToFloatDevice above) -- one pass over the PCIe link, four pixels per lane (16-byte reads), no staging
-// copy of the raw colour.  Takes the place of the two uploads + the conversion of CUDARGBDAdapter::process
-// (DSC/CUDARGBDAdapter.cpp:107-131) for a frame at adapter resolution.
-__global__ __launch_bounds__(256) void k_upload_frame(const uint4* hostDepth, const uint4* hostRGBX, uint4* depth, float4* color, uint32_t nQuads, uint32_t n)
+// (convertColorRawToFloatDevice above) -- one pass over the PCIe link, four pixels per 16-byte read, no staging copy of
+// the raw colour.  Takes the place of the two uploads + the conversion of CUDARGBDAdapter::process
+// (DSC/CUDARGBDAdapter.cpp:107-131) for a frame at adapter resolution.  The link, not the machine, sets the time
+// (2.4 MB at ~45 GB/s = 55 us), so the grid is small and each lane keeps four reads in flight: the kernel runs beside
+// the frame loop's own launches on another stream.
+constexpr uint32_t kUploadInFlight = 4;
+#ifndef VH_UPLOAD_GROUPS
+#define VH_UPLOAD_GROUPS 16
+#endif
+// Measured, frames/s of the host-fed loop at 640x480 (the frame loop runs beside this kernel): 1 workgroup 1 860,
+// 2: 3 310, 4: 5 710, 8: 9 440, 16: 11 700, 300: 9 300.  A read over the link takes ~3.3 us to come back, so few lanes
+// cannot fill it (one workgroup moves 4.9 GB/s); and however small the kernel is, k_render runs two to three times
+// slower while reads of host memory are in flight (36 -> 63 us beside 16 workgroups, 116 us beside ONE that takes
+// 500 us): it is the uncached reads themselves, not the wave slots, that get in the way.  Sixteen workgroups is the
+// best trade found; a copy engine (hipMemcpyAsync from pinned memory) would not touch the shader's memory path at all,
+// but needs an event pair per frame on the frame loop's stream.
+constexpr uint32_t kUploadGroups = VH_UPLOAD_GROUPS;
+__global__ __launch_bounds__(256) void k_upload_frame(const uint4* hostDepth, const uint4* hostRGBX, uint4* depth, float4* color, uint32_t nQuads)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nQuads) return;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 dn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&hostDepth[i]));
-    const uint4 d = make_uint4(dn.x, dn.y, dn.z, dn.w);
-    if (4u * i + 3u < n) depth[i] = d;
-    else {
-        const uint32_t dv[4] = { d.x, d.y, d.z, d.w };
-        for (uint32_t k = 0; 4u * i + k < n; k++) reinterpret_cast<uint32_t*>(depth)[4u * i + k] = dv[k];
-    }
-    if (!hostRGBX) return;
-    const u32x4 cn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&hostRGBX[i]));
-    const uint4 c4 = make_uint4(cn.x, cn.y, cn.z, cn.w);
-    const uint32_t cv[4] = { c4.x, c4.y, c4.z, c4.w };
     const float mi = minf();
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nQuads; i0 += stride * kUploadInFlight) {
+        u32x4 d[kUploadInFlight], c[kUploadInFlight];
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) {
-        if (4u * i + k >= n) break;
-        const uint32_t c = cv[k];
-        const uint32_t r = c & 0xffu, g = (c >> 8) & 0xffu, b = (c >> 16) & 0xffu, w = c >> 24;
-        color[4u * i + k] = (r == 0u && g == 0u && b == 0u) ? make_float4(mi, mi, mi, mi)
-                                                            : make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)(w / 255u));
+        for (uint32_t k = 0; k < kUploadInFlight; k++) {
+            const uint32_t i = i0 + k * stride;
+            d[k] = u32x4{ 0u, 0u, 0u, 0u };
+            c[k] = u32x4{ 0u, 0u, 0u, 0u };
+            if (i < nQuads) {
+                d[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&hostDepth[i]));
+                if (hostRGBX) c[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&hostRGBX[i]));
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kUploadInFlight; k++) {
+            const uint32_t i = i0 + k * stride;
+            if (i >= nQuads) continue;
+            depth[i] = make_uint4(d[k].x, d[k].y, d[k].z, d[k].w);
+            if (!hostRGBX) continue;
+            const uint32_t cv[4] = { c[k].x, c[k].y, c[k].z, c[k].w };
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t px = cv[j];
+                const uint32_t r = px & 0xffu, g = (px >> 8) & 0xffu, b = (px >> 16) & 0xffu, w = px >> 24;
+                color[4u * i + j] = (r == 0u && g == 0u && b == 0u) ? make_float4(mi, mi, mi, mi)
+                                                                    : make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)(w / 255u));
+            }
+        }
     }
 }
 
@@ -3158,8 +3180,9 @@ int vh_upload_frame(const float* hostDepth, const uint8_t* hostRGBX, float* d_de
     // multiple of four pixels (640x480 and every even-by-even size is)
     if (n % 4u) return VH_ERR_BAD_ARGUMENT;
     const uint32_t nQuads = n / 4u;
-    k_upload_frame<<<cdiv(nQuads, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const uint4*>(hostDepth), reinterpret_cast<const uint4*>(hostRGBX),
-                                                                     reinterpret_cast<uint4*>(d_depth), reinterpret_cast<float4*>(d_color4), nQuads, n);
+    const uint32_t want = cdiv(nQuads, 256u * kUploadInFlight);
+    k_upload_frame<<<want < kUploadGroups ? want : kUploadGroups, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const uint4*>(hostDepth), reinterpret_cast<const uint4*>(hostRGBX),
+                                                                            reinterpret_cast<uint4*>(d_depth), reinterpret_cast<float4*>(d_color4), nQuads);
     return vh_last_launch_error();
 }
 

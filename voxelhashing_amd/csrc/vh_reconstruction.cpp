@@ -77,22 +77,22 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
     if (options.s_streamingEnabled && !chunkGrid) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: streaming needs a chunk grid");
     if (options.s_renderEnabled && !rayCast) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: rendering needs a ray caster");
     std::memset(&m_stats, 0, sizeof(m_stats));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kStagingSlots; i++) {
         d_stageDepth[i] = nullptr; d_stageColorRaw[i] = nullptr; d_stageColor[i] = nullptr;
-        m_slotReady[i] = m_slotFree[i] = nullptr;
-        m_slotUsed[i] = false;
+        m_slotReady[i] = nullptr;
+        m_slotSceneFrame[i] = 0;
     }
+    m_uploads = 0;
     if (m_opt.s_framesOnHost) {
         const size_t n = (size_t)cp.m_imageWidth * cp.m_imageHeight;
         hipStream_t cs = nullptr;
         checkHip(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
         m_copyStream = (void*)cs;
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < kStagingSlots; i++) {
             checkHip(hipMalloc((void**)&d_stageDepth[i], sizeof(float) * (n ? n : 1)), "staging depth");
             checkHip(hipMalloc((void**)&d_stageColorRaw[i], 4 * (n ? n : 1)), "staging colour (raw)");
             checkHip(hipMalloc((void**)&d_stageColor[i], sizeof(float) * 4 * (n ? n : 1)), "staging colour");
             m_slotReady[i] = (void*)newEvent(false);
-            m_slotFree[i] = (void*)newEvent(false);
         }
         m_stats.uploadBytes = (sizeof(float) + 4) * n;
     }
@@ -103,9 +103,8 @@ Reconstruction::~Reconstruction()
     try { synchronize(); } catch (...) {}
     for (auto& p : m_uploadTimers) { (void)hipEventDestroy((hipEvent_t)p.first); (void)hipEventDestroy((hipEvent_t)p.second); }
     for (void* e : m_timerPool) (void)hipEventDestroy((hipEvent_t)e);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kStagingSlots; i++) {
         if (m_slotReady[i]) (void)hipEventDestroy((hipEvent_t)m_slotReady[i]);
-        if (m_slotFree[i]) (void)hipEventDestroy((hipEvent_t)m_slotFree[i]);
         if (d_stageDepth[i]) (void)hipFree(d_stageDepth[i]);
         if (d_stageColorRaw[i]) (void)hipFree(d_stageColorRaw[i]);
         if (d_stageColor[i]) (void)hipFree(d_stageColor[i]);
@@ -128,7 +127,7 @@ void Reconstruction::reset()
     std::memset(&m_stats, 0, sizeof(m_stats));
     m_stats.uploadBytes = bytes;
     m_frameNumber = 0;
-    m_slotUsed[0] = m_slotUsed[1] = false;
+    for (int i = 0; i < kStagingSlots; i++) m_slotSceneFrame[i] = 0;
 }
 
 const ReconstructionStats& Reconstruction::getStats()
@@ -146,27 +145,51 @@ const ReconstructionStats& Reconstruction::getStats()
     return m_stats;
 }
 
-// CUDARGBDAdapter::process :107-131 for a frame at adapter resolution: upload, colour bytes -> float4
+// CUDARGBDAdapter::process :107-131 for a frame at adapter resolution: upload, colour bytes -> float4.  The copy
+// stream runs beside the frame loop's stream; the only thing the main stream does for an upload is to wait for its
+// "ready" event (a record on the main stream would idle it for ~6 us per frame).  A staging slot is reused once the
+// frame that read it last has been integrated, which the host sees in the scene's mapped frame counter: the pass over
+// the voxels of the NEXT frame has started.
 DepthCameraData Reconstruction::upload(const SequenceFrame& f)
 {
-    const unsigned int slot = m_frameNumber & 1u;
+    const unsigned int slot = m_uploads % kStagingSlots;
     const size_t n = (size_t)m_cp.m_imageWidth * m_cp.m_imageHeight;
     hipStream_t cs = (hipStream_t)m_copyStream, ms = (hipStream_t)m_sceneRep->getStream();
-    // the slot is free once the frame that used it last has been integrated
-    if (m_slotUsed[slot]) checkHip(hipStreamWaitEvent(cs, (hipEvent_t)m_slotFree[slot], 0), "hipStreamWaitEvent");
+    if (m_slotSceneFrame[slot] != 0) {
+        // the slot's last frame was the scene's frame number m_slotSceneFrame[slot]: done once a later frame's pass has started
+        const unsigned int need = m_slotSceneFrame[slot] + 1u;
+        const double w0 = now();
+        bool waited = false;
+        const VhSceneOptions& so = m_sceneRep->getOptions();
+        const bool mirrored = m_opt.s_integrationEnabled && !so.s_useReferenceLaunchSequence; // only the fused pass keeps the counter
+        while (m_sceneRep->getNumFramesStartedOnDevice() < need) {
+            if (!mirrored || m_sceneRep->getNumIntegratedFrames() < need) { // nothing later has been enqueued: only a synchronisation tells
+                checkHip(hipStreamSynchronize(ms), "hipStreamSynchronize");
+                break;
+            }
+            std::this_thread::yield();
+            waited = true;
+            if (now() - w0 > 30.0) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: the device made no progress for 30 s");
+        }
+        if (waited) m_stats.hostWaitSeconds += now() - w0;
+    }
     auto timerEvent = [&]() {
         if (!m_timerPool.empty()) { void* e = m_timerPool.back(); m_timerPool.pop_back(); return e; }
         return (void*)newEvent(true);
     };
-    void* t0 = timerEvent();
-    void* t1 = timerEvent();
+    const bool timed = (m_uploads % 8u) == 0u; // (a timed pair idles the copy stream twice)
+    void *t0 = nullptr, *t1 = nullptr;
     // Pinned (device-visible) frames are read by a kernel straight over the link, colour converted on the way; anything
     // else goes through hipMemcpyAsync (staged by the runtime) and the conversion kernel of the sensor path.
     void *devDepth = nullptr, *devColor = nullptr;
     const bool mapped = (n % 4u) == 0u && hipHostGetDevicePointer(&devDepth, const_cast<float*>(f.depth), 0) == hipSuccess &&
                         (!f.color || hipHostGetDevicePointer(&devColor, const_cast<void*>(f.color), 0) == hipSuccess);
     if (!mapped) (void)hipGetLastError();
-    checkHip(hipEventRecord((hipEvent_t)t0, cs), "hipEventRecord");
+    if (timed) {
+        t0 = timerEvent();
+        t1 = timerEvent();
+        checkHip(hipEventRecord((hipEvent_t)t0, cs), "hipEventRecord");
+    }
     if (mapped) {
         check(vh_upload_frame((const float*)devDepth, (const uint8_t*)devColor, d_stageDepth[slot], d_stageColor[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "vh_upload_frame");
     } else {
@@ -176,11 +199,14 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
             check(vh_convert_color_raw_to_float4(d_stageColor[slot], d_stageColorRaw[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "convertColorRawToFloat4");
         }
     }
-    checkHip(hipEventRecord((hipEvent_t)t1, cs), "hipEventRecord");
-    m_uploadTimers.emplace_back(t0, t1);
+    if (timed) {
+        checkHip(hipEventRecord((hipEvent_t)t1, cs), "hipEventRecord");
+        m_uploadTimers.emplace_back(t0, t1);
+    }
     checkHip(hipEventRecord((hipEvent_t)m_slotReady[slot], cs), "hipEventRecord");
     checkHip(hipStreamWaitEvent(ms, (hipEvent_t)m_slotReady[slot], 0), "hipStreamWaitEvent");
-    m_slotUsed[slot] = true;
+    m_slotSceneFrame[slot] = m_sceneRep->getNumIntegratedFrames() + 1u; // the scene frame this upload feeds
+    m_uploads++;
     DepthCameraData cam;
     std::memset(&cam, 0, sizeof(cam));
     cam.d_depthData = d_stageDepth[slot];
@@ -252,8 +278,6 @@ void Reconstruction::frame(const SequenceFrame& f)
     } else {
         m_sceneRep->setLastRigidTransformAndCompactify(transformation, m_cp); // :907
     }
-    if (m_opt.s_framesOnHost)
-        checkHip(hipEventRecord((hipEvent_t)m_slotFree[m_frameNumber & 1u], (hipStream_t)m_sceneRep->getStream()), "hipEventRecord");
     m_frameNumber++;
     m_stats.frames++;
 }

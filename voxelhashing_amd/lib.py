@@ -26,6 +26,8 @@ PROTOTYPES = {
     "vh_last_error_message": (C.c_char_p, []),
     "vh_malloc": (C.c_int, [P(_VP), C.c_size_t]),
     "vh_free": (C.c_int, [_VP]),
+    "vh_malloc_host": (C.c_int, [P(_VP), C.c_size_t]),
+    "vh_free_host": (C.c_int, [_VP]),
     "vh_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "vh_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "vh_memset": (C.c_int, [_VP, C.c_int, C.c_size_t, _VP]),
@@ -260,6 +262,39 @@ class DeviceBuffer:
     def free(self):
         if getattr(self, "ptr", None):
             load().vh_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A numpy array in pinned, device-visible host memory (vh_malloc_host)."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(int(v) for v in np.atleast_1d(shape))
+        n = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(load().vh_malloc_host(C.byref(p), max(n, 1)), "vh_malloc_host")
+        self.ptr = p.value
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        p = cls(a.shape, a.dtype)
+        p.array[...] = a
+        return p
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            load().vh_free_host(self.ptr)
             self.ptr = None
 
     def __del__(self):
