@@ -603,8 +603,9 @@ def main(argv=None):
             ups = max(h1["uploadsTimed"] - h0["uploadsTimed"], 1)
             result["value_with_upload"] = round(hs / dt, 3)
             result["upload"] = dict(frames=hs, upload_us=round(1e3 * (h1["uploadMs"] - h0["uploadMs"]) / ups, 3), bytes_per_frame=int(h1["uploadBytes"]),
-                                    how="pinned host frames (float depth + RGBX colour), hipMemcpyAsync on a copy stream into two staging slots, "
-                                        "colour converted on the device; the upload of frame k+1 runs beside frame k")
+                                    how="pinned host frames (float depth + RGBX colour), hipMemcpyAsync on two copy streams (one copy engine each) into a ring of "
+                                        "four staging slots, colour converted on the device; uploads run beside the frame loop, which only waits for "
+                                        "their events; upload_us is the colour copy + conversion, every 8th frame timed")
             hl.close()
             del hl
             torch.cuda.empty_cache()

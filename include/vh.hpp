@@ -406,7 +406,9 @@ private:
     float* d_stageDepth[kStagingSlots];
     unsigned char* d_stageColorRaw[kStagingSlots];
     float* d_stageColor[kStagingSlots];
+    void* m_copyStream2;                          // the depth copy runs on a stream (a copy engine) of its own
     void* m_slotReady[kStagingSlots];             // copy stream -> main stream
+    void* m_slotReady2[kStagingSlots];
     unsigned int m_slotSceneFrame[kStagingSlots]; // the scene's frame count when the slot's frame was enqueued, + 1 (0: never used)
     unsigned int m_uploads;                       // frames uploaded so far (the slot is m_uploads % kStagingSlots)
     std::vector<std::pair<void*, void*>> m_uploadTimers; // event pairs on the copy stream, not yet read

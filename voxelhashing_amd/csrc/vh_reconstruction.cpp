@@ -17,6 +17,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -71,7 +72,7 @@ ReconstructionOptions Reconstruction::defaultOptions()
 
 Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* rayCast, CUDASceneRepChunkGrid* chunkGrid,
                                const DepthCameraParams& cp, const ReconstructionOptions& options)
-    : m_sceneRep(sceneRep), m_rayCast(rayCast), m_chunkGrid(chunkGrid), m_cp(cp), m_opt(options), m_frameNumber(0), m_copyStream(nullptr)
+    : m_sceneRep(sceneRep), m_rayCast(rayCast), m_chunkGrid(chunkGrid), m_cp(cp), m_opt(options), m_frameNumber(0), m_copyStream(nullptr), m_copyStream2(nullptr)
 {
     if (!sceneRep) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: no scene");
     if (options.s_streamingEnabled && !chunkGrid) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: streaming needs a chunk grid");
@@ -79,7 +80,7 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
     std::memset(&m_stats, 0, sizeof(m_stats));
     for (int i = 0; i < kStagingSlots; i++) {
         d_stageDepth[i] = nullptr; d_stageColorRaw[i] = nullptr; d_stageColor[i] = nullptr;
-        m_slotReady[i] = nullptr;
+        m_slotReady[i] = m_slotReady2[i] = nullptr;
         m_slotSceneFrame[i] = 0;
     }
     m_uploads = 0;
@@ -88,11 +89,15 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
         hipStream_t cs = nullptr;
         checkHip(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
         m_copyStream = (void*)cs;
+        hipStream_t cs2 = nullptr;
+        checkHip(hipStreamCreateWithFlags(&cs2, hipStreamNonBlocking), "hipStreamCreate");
+        m_copyStream2 = (void*)cs2;
         for (int i = 0; i < kStagingSlots; i++) {
             checkHip(hipMalloc((void**)&d_stageDepth[i], sizeof(float) * (n ? n : 1)), "staging depth");
             checkHip(hipMalloc((void**)&d_stageColorRaw[i], 4 * (n ? n : 1)), "staging colour (raw)");
             checkHip(hipMalloc((void**)&d_stageColor[i], sizeof(float) * 4 * (n ? n : 1)), "staging colour");
             m_slotReady[i] = (void*)newEvent(false);
+            m_slotReady2[i] = (void*)newEvent(false);
         }
         m_stats.uploadBytes = (sizeof(float) + 4) * n;
     }
@@ -105,16 +110,19 @@ Reconstruction::~Reconstruction()
     for (void* e : m_timerPool) (void)hipEventDestroy((hipEvent_t)e);
     for (int i = 0; i < kStagingSlots; i++) {
         if (m_slotReady[i]) (void)hipEventDestroy((hipEvent_t)m_slotReady[i]);
+        if (m_slotReady2[i]) (void)hipEventDestroy((hipEvent_t)m_slotReady2[i]);
         if (d_stageDepth[i]) (void)hipFree(d_stageDepth[i]);
         if (d_stageColorRaw[i]) (void)hipFree(d_stageColorRaw[i]);
         if (d_stageColor[i]) (void)hipFree(d_stageColor[i]);
     }
     if (m_copyStream) (void)hipStreamDestroy((hipStream_t)m_copyStream);
+    if (m_copyStream2) (void)hipStreamDestroy((hipStream_t)m_copyStream2);
 }
 
 void Reconstruction::synchronize()
 {
     if (m_copyStream) checkHip(hipStreamSynchronize((hipStream_t)m_copyStream), "hipStreamSynchronize");
+    if (m_copyStream2) checkHip(hipStreamSynchronize((hipStream_t)m_copyStream2), "hipStreamSynchronize");
     // the scene's side stream joins the main stream in integrateFinish(): the main stream is the last to finish
     checkHip(hipStreamSynchronize((hipStream_t)m_sceneRep->getStream()), "hipStreamSynchronize");
 }
@@ -179,12 +187,16 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
     };
     const bool timed = (m_uploads % 8u) == 0u; // (a timed pair idles the copy stream twice)
     void *t0 = nullptr, *t1 = nullptr;
-    // Pinned (device-visible) frames are read by a kernel straight over the link, colour converted on the way; anything
-    // else goes through hipMemcpyAsync (staged by the runtime) and the conversion kernel of the sensor path.
+    // The frame travels by the copy engines (hipMemcpyAsync: depth on one stream, colour on another, so that each gets
+    // an engine), then the colour is converted as in the sensor path.  Reading the pinned frame from a kernel instead
+    // (vh_upload_frame: one pass, no raw-colour staging) was measured slower for the loop as a whole: while uncached
+    // reads of host memory are in flight every other kernel's memory accesses queue behind them, and k_render takes
+    // two to three times as long (vh_kernels.hip, k_upload_frame; VH_UPLOAD_KERNEL=1 selects that path for measurement).
+    static const bool useKernel = std::getenv("VH_UPLOAD_KERNEL") != nullptr;
     void *devDepth = nullptr, *devColor = nullptr;
-    const bool mapped = (n % 4u) == 0u && hipHostGetDevicePointer(&devDepth, const_cast<float*>(f.depth), 0) == hipSuccess &&
+    const bool mapped = useKernel && (n % 4u) == 0u && hipHostGetDevicePointer(&devDepth, const_cast<float*>(f.depth), 0) == hipSuccess &&
                         (!f.color || hipHostGetDevicePointer(&devColor, const_cast<void*>(f.color), 0) == hipSuccess);
-    if (!mapped) (void)hipGetLastError();
+    if (useKernel && !mapped) (void)hipGetLastError();
     if (timed) {
         t0 = timerEvent();
         t1 = timerEvent();
@@ -193,7 +205,11 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
     if (mapped) {
         check(vh_upload_frame((const float*)devDepth, (const uint8_t*)devColor, d_stageDepth[slot], d_stageColor[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "vh_upload_frame");
     } else {
-        checkHip(hipMemcpyAsync(d_stageDepth[slot], f.depth, sizeof(float) * n, hipMemcpyHostToDevice, cs), "upload depth");
+        // two copies, two streams: each gets a copy engine of its own
+        hipStream_t cs2 = (hipStream_t)m_copyStream2;
+        checkHip(hipMemcpyAsync(d_stageDepth[slot], f.depth, sizeof(float) * n, hipMemcpyHostToDevice, cs2), "upload depth");
+        checkHip(hipEventRecord((hipEvent_t)m_slotReady2[slot], cs2), "hipEventRecord");
+        checkHip(hipStreamWaitEvent(ms, (hipEvent_t)m_slotReady2[slot], 0), "hipStreamWaitEvent");
         if (f.color) {
             checkHip(hipMemcpyAsync(d_stageColorRaw[slot], f.color, 4 * n, hipMemcpyHostToDevice, cs), "upload colour");
             check(vh_convert_color_raw_to_float4(d_stageColor[slot], d_stageColorRaw[slot], m_cp.m_imageWidth, m_cp.m_imageHeight, m_copyStream), "convertColorRawToFloat4");
