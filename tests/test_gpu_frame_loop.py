@@ -179,6 +179,51 @@ def test_splat_made_ahead_is_dropped_when_the_table_changes(E, oracle_lib):
     assert (ray.download()["depth"] != -np.inf).sum() > 500
 
 
+@pytest.mark.parametrize("width,height", [(203, 149), (64, 48), (9, 7)])
+def test_ragged_image_sizes_through_the_co_launches(E, oracle_lib, width, height):
+    """image sizes that are no multiple of the 8x8 tiles (and one smaller than two tiles), no colour on some frames, zero
+    frames in a call: the riders' workgroup arithmetic (alloc tiles behind the ray caster's, compactify and splat behind
+    computeNormals') must not depend on round numbers"""
+    O = oracle_lib
+    hp, cp, rp = small_config(width, height, num_buckets=1 << 16, num_sdf_blocks=1 << 11)
+    n = 6
+    poses = [shifted_pose(k, 80) for k in range(n)]
+    frames, host = make_inputs(E, O, cp, poses, SHIFTED_S1, 0)
+    assert oracle_online_is_deterministic(O, hp, cp, rp, poses, host, True, 2)
+    opt = T.make_scene_options(offline=False, gc=True, starve=2)
+    scene, ray, ref = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp), O.OracleScene(hp, cp, rp, opt)
+    recon = E.Reconstruction(scene, ray, None, cp)
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+    recon.run(seq, 0, 0)  # nothing to do
+    for k in range(n):
+        recon.run(seq, k, 1)
+        recon.synchronize()
+        if k > 0:
+            assert_maps_equal(ray.download(), ref.render(poses[k - 1]), f"{width}x{height} frame {k}")
+        ref.integrate(poses[k], host[k][0], host[k][1])
+        canonical.assert_same_scene(scene.state(), ref.state(), f"{width}x{height} frame {k}")
+
+
+def test_frames_without_colour_integrate_nothing(E, oracle_lib):
+    """integrateDepthMapKernel reads the colour first and integrates only where it is valid
+    (DSC/CUDASceneRepHashSDF.cu:443): a frame without a colour map allocates its blocks and integrates nothing"""
+    O = oracle_lib
+    hp, cp, rp = small_config(96, 72)
+    poses = [shifted_pose(k, 60) for k in range(3)]
+    opt = T.make_scene_options(offline=True, gc=False)
+    scene, ray, ref = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp), O.OracleScene(hp, cp, rp, opt)
+    recon = E.Reconstruction(scene, ray, None, cp)
+    frames = [E.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [None, frames[1].color_ptr, None])
+    recon.run(seq)
+    recon.synchronize()
+    for k, p in enumerate(poses):
+        d, c = O.synth_frame(SHIFTED_S1, 0, p, cp)
+        ref.integrate(p, d, c if k == 1 else None)
+    canonical.assert_same_scene(scene.state(), ref.state(), "colour on the middle frame only")
+    assert (scene.state()["voxels"]["weight"] > 0).sum() > 100
+
+
 def test_invalid_pose_is_skipped_and_loop_can_restart(E, oracle_lib):
     """DSC/DepthSensing.cpp:738-741: a frame whose recorded pose starts with -inf / NaN is not processed"""
     O = oracle_lib

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/${1:-r02r}
+O=gpurun_out/${1:-r02s}
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q --timeout 120 > $O/pytest_gpu.log 2>&1; rc=$?; echo "pytest gpu rc=$rc" | tee -a $O/summary.txt
 tail -4 $O/pytest_gpu.log
