@@ -1800,6 +1800,15 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
 {
     __shared__ SplatShared sh;
     uint32_t g = blockIdx.x;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 31 // measurement builds: the riders of this launch, one at a time
+    if (g == 0u && splat.groups > splat.nSplatGroups) return; // no schedule workgroup
+#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 32
+    if (g < splat.groups) return; // no splat at all
+#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 33
+    if (g >= splat.groups && g - splat.groups < job.groups) return; // no compactify
+#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 34
+    if (g >= splat.groups + job.groups) return; // no normals
+#endif
     if (g < splat.groups) {
         // the schedule workgroup first (one workgroup sorts all tiles: the longest chain), then the table's slices
         const bool withSchedule = splat.groups > splat.nSplatGroups;
