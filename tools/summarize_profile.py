@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of one evidence run into the summaries kept under profiles/.
+"""Turns the rocprofv3 outputs of one evidence run (tools/collect_profile.sh -> gpurun_out/final/) into the summaries
+kept under profiles/.
 
     python tools/summarize_profile.py <run dir> <tag>
 
-<run dir> holds trace/p_kernel_stats.csv (--kernel-trace --stats of the default bench command) and
-pmc_FETCH_SIZE/, pmc_WRITE_SIZE/, pmc_TCC_HIT_sum_TCC_MISS_sum/ (one --pmc pass each, p_counter_collection.csv), plus
-the bench lines bench*.json.  Writes profiles/<tag>_bench_kernel_stats.csv, profiles/<tag>_bench_pmc_hbm_l2.csv,
-profiles/<tag>_bench_line*.json and refreshes profiles/traffic.json (k_render: (2*FETCH_SIZE + WRITE_SIZE) KB, FETCH
-doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
+Writes profiles/<tag>_bench_kernel_stats.csv and <tag>_dense_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the
+default bench command and of the dense-scene run), <tag>_bench_pmc.csv and <tag>_dense_pmc.csv (per-kernel averages of
+the counters, one --pmc pass each), <tag>_bench_line*.json (the bench lines) and profiles/traffic.json (HBM bytes per
+launch of the kernels the bench prices: 2 * FETCH_SIZE + WRITE_SIZE, FETCH doubled for gfx950 as MI355X_MICROARCH.md
+prescribes for wide reads)."""
 import collections
 import csv
 import glob
@@ -25,47 +26,76 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
 
+def pmc_table(run, prefix):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(run, prefix + "_*"))):
+        f = os.path.join(d, "p_counter_collection.csv")
+        if os.path.isdir(d) and os.path.exists(f):
+            for r in csv.DictReader(open(f)):
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for k in acc for c in acc[k]})
+    rows = []
+    for k in sorted(acc):
+        n = max(len(v) for v in acc[k].values())
+        if n < 5:
+            continue
+        row = {"kernel": k, "dispatches": n}
+        for c in counters:
+            v = acc[k].get(c, [])
+            v = v[len(v) // 4:]  # the first quarter is warm-up
+            row[c] = round(sum(v) / len(v), 1) if v else ""
+        if row.get("TCC_HIT_sum") != "" and row.get("TCC_MISS_sum") != "":
+            h, m = row["TCC_HIT_sum"], row["TCC_MISS_sum"]
+            row["l2_hit_rate"] = round(h / (h + m), 3) if h + m else ""
+        if row.get("FETCH_SIZE") != "" and row.get("WRITE_SIZE") != "":
+            row["hbm_bytes_2xFETCH_plus_WRITE"] = int(round((2 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024))
+        rows.append(row)
+    return rows, counters
+
+
+def write_table(path, rows, counters):
+    cols = ["kernel", "dispatches"] + counters + ["l2_hit_rate", "hbm_bytes_2xFETCH_plus_WRITE"]
+    with open(path, "w") as o:
+        o.write(",".join(cols) + "\n")
+        for r in rows:
+            o.write(",".join(str(r.get(c, "")) for c in cols) + "\n")
+
+
 def main():
     run, tag = sys.argv[1], sys.argv[2]
     prof = os.path.join(ROOT, "profiles")
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_TCC_HIT_sum_TCC_MISS_sum"):
-        for r in csv.DictReader(open(os.path.join(run, d, "p_counter_collection.csv"))):
-            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    avg = lambda l: sum(l) / len(l) if l else 0.0
-    rows = []
-    for k in sorted(acc):
-        a = acc[k]
-        f, w, h, m = (avg(a.get(c, [])) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"))
-        rows.append((k, len(a.get("FETCH_SIZE", [])), round(f, 1), round(w, 1), round(h), round(m), round(h / (h + m), 3) if h + m else ""))
-    with open(os.path.join(prof, f"{tag}_bench_pmc_hbm_l2.csv"), "w") as o:
-        o.write("kernel,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,TCC_HIT_sum_avg,TCC_MISS_sum_avg,l2_hit_rate\n")
-        for r in rows:
-            o.write(",".join(map(str, r)) + "\n")
-    shutil.copy(os.path.join(run, "trace", "p_kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
+    traffic = {}
+    for what, prefix, trace in (("bench", "pmc", "trace"), ("dense", "pmcdense", "trace_dense")):
+        rows, counters = pmc_table(run, prefix)
+        write_table(os.path.join(prof, f"{tag}_{what}_pmc.csv"), rows, counters)
+        shutil.copy(os.path.join(run, trace, "p_kernel_stats.csv"), os.path.join(prof, f"{tag}_{what}_kernel_stats.csv"))
+        stats = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(run, trace, "p_kernel_stats.csv")))}
+        print(f"\n### {what}\n| kernel | calls | avg us | % | FETCH KB (raw) | WRITE KB | L2 hit | VALU insts | VALU busy (quad-cycles) |")
+        pm = {r["kernel"]: r for r in rows}
+        for k, r in stats.items():
+            if float(r["Percentage"]) > 0.5:
+                p = pm.get(k, {})
+                print(f"| {k} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} | {p.get('FETCH_SIZE', '')} | {p.get('WRITE_SIZE', '')} | "
+                      f"{p.get('l2_hit_rate', '')} | {p.get('SQ_INSTS_VALU', '')} | {p.get('SQ_ACTIVE_INST_VALU', '')} |")
+        traffic[what] = {r["kernel"]: r.get("hbm_bytes_2xFETCH_plus_WRITE") for r in rows if r.get("hbm_bytes_2xFETCH_plus_WRITE")}
+    traffic["_note"] = (f"HBM bytes per launch from profiles/{tag}_*_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                        "(gfx950 reports half of wide reads; gathers are uncalibrated, so this is an upper bound); separate --pmc passes.  bench.py does "
+                        "not copy these numbers into its line: `traffic` there is null unless counters ran in that very run.")
+    json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     for f in glob.glob(os.path.join(run, "bench*.json")):
         n = os.path.basename(f)[len("bench"):]
         if n != "_under_profiler.json":
-            shutil.copy(f, os.path.join(prof, f"{tag}_bench_line{n}"))
-    rk = [r for r in rows if r[0].startswith("k_render")][0]
-    tpath = os.path.join(prof, "traffic.json")
-    t = json.load(open(tpath))
-    t["cfg2"].update(raycast=int(round((2 * rk[2] + rk[3]) * 1024)), fetch_kb_raw=rk[2], write_kb=rk[3])
-    t["cfg2"]["_note"] = (f"k_render per launch (profiles/{tag}_*): (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes; FETCH_SIZE doubled per "
-                          "MI355X_MICROARCH.md (gfx950 reports half of wide reads; the 8-byte gathers of this kernel are uncalibrated, so this is "
-                          "an upper bound); separate --pmc passes, see profiles/README.md")
-    json.dump(t, open(tpath, "w"), indent=1)
-    total = 0.0
-    print("| kernel | calls | avg us | % | FETCH KB | WRITE KB | L2 hit |")
-    pm = {r[0]: r for r in rows}
-    for r in csv.DictReader(open(os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))):
-        if float(r["Percentage"]) > 0.5:
-            k = short(r["Name"])
-            p = pm.get(k, ("", 0, "", "", "", "", ""))
-            print(f"| {k} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} | {p[2]} | {p[3]} | {p[6]} |")
+            lines = [l for l in open(f) if l.startswith("{")]
+            if lines:
+                open(os.path.join(prof, f"{tag}_bench_line{n}"), "w").write(lines[-1])
+    print()
     for f in sorted(glob.glob(os.path.join(run, "bench*.json"))):
-        d = json.load(open(f))
-        print(os.path.basename(f), d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["roofline"]["traffic"], d.get("cpu_baseline"))
+        lines = [l for l in open(f) if l.startswith("{")]
+        if not lines:
+            continue
+        d = json.loads(lines[-1])
+        print(os.path.basename(f), d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d.get("value_with_upload"),
+              (d.get("rooflines") or {}).get("integrate_dense", {}).get("frac"), (d.get("cpu_baseline") or {}).get("value"))
 
 
 if __name__ == "__main__":
