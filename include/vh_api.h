@@ -207,6 +207,11 @@ int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_
  * operands (of n pseudo-random ones) where the shortcut differs from `/` / `%`. */
 int vh_debug_check_fast_math(float divisor, uint32_t modulus, uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream);
 
+/* Self-check of the division the fused integrate pass uses for blocks it has certified (one refined reciprocal shared by
+ * the two perspective divisions of a voxel; the same for the blend's division by the weight sum): n pseudo-random
+ * operand pairs inside the certified ranges against `/`.  d_mismatches[0]: projection range, [1]: blend range. */
+int vh_debug_check_refined_division(uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream);
+
 /* ---- host classes (opaque handles over the C++ classes of include/vh.hpp) ---- */
 typedef struct VhSceneRep VhSceneRep;   /* CUDASceneRepHashSDF,   DSC/CUDASceneRepHashSDF.h:28 */
 typedef struct VhRayCast VhRayCast;     /* CUDARayCastSDF,        DSC/CUDARayCastSDF.h:13 */

@@ -59,3 +59,84 @@ def test_workgroup_per_block_shape_without_gc(E, oracle_lib):
     opt = T.make_scene_options(offline=True, gc=False)
     most = run(E, oracle_lib, hp, cp, rp, "S3", 5, 100, opt)
     assert 50 < most < 2048
+
+
+def test_certified_blocks_with_crafted_voxels(E, oracle_lib):
+    """Blocks whose corners pass the certificate take integrate_block_certified (shared refined reciprocals, packed
+    arithmetic, pixel from the staged tile).  Its blend division leaves the fast route for numerators outside
+    [2^-100, 2^90): blocks streamed in with denormal, tiny, huge and signed-zero sdf values and every kind of weight sit
+    in the free space in front of a wall, where every voxel integrates.  Launcher level, against the oracle."""
+    import ctypes as C
+    from voxelhashing_amd.lib import DeviceBuffer
+    O = oracle_lib
+    hp, cp, rp = small_config(160, 120, params="P2", num_buckets=1 << 12, num_sdf_blocks=2048)
+    rng = np.random.default_rng(20260)
+    W, H = cp.m_imageWidth, cp.m_imageHeight
+    depth = np.full((H, W), 2.5, np.float32) + rng.uniform(-0.02, 0.02, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.03] = -np.inf
+    color = np.concatenate([rng.random((H, W, 3), dtype=np.float32), np.ones((H, W, 1), np.float32)], axis=2)
+    color[rng.random((H, W)) < 0.02, :3] = -np.inf
+    # a camera pose with every rotation axis in play, away from the origin
+    a, b, c = np.radians([17.0, -23.0, 9.0])
+    rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    pose = np.eye(4)
+    pose[:3, :3] = rz @ ry @ rx
+    pose[:3, 3] = [3.1, -1.7, 2.3]
+    pose = pose.astype(np.float32).reshape(16)
+
+    # crafted blocks in front of the wall
+    z = rng.uniform(0.9, 2.1, 600)
+    pts = np.stack([rng.uniform(-0.4, 0.4, 600) * z, rng.uniform(-0.3, 0.3, 600) * z, z, np.ones(600)], axis=1)
+    ids = np.unique(np.floor((pts @ pose.reshape(4, 4).astype(np.float64).T)[:, :3] / (8 * hp.m_virtualVoxelSize)).astype(np.int32), axis=0)[:200]
+    assert len(ids) > 150, len(ids)
+    special = np.array([0.0, -0.0, 1e-45, -1e-40, 1e-35, -3e-31, 5e-31, 1e-30, 1.5, -0.07, 0.2, 1e26, -4.7e24, 6e24, 2e28, -1e38, 3e38], np.float32)
+    blocks = np.zeros((len(ids), T.SDF_BLOCK_VOXELS), T.VOXEL_DTYPE)
+    pick = rng.random(blocks.shape)
+    blocks["sdf"] = np.where(pick < 0.5, special[rng.integers(0, len(special), blocks.shape)], rng.normal(0, 0.2, blocks.shape).astype(np.float32))
+    blocks["weight"] = np.array([0, 1, 2, 3, 127, 128, 254, 255], np.uint8)[rng.integers(0, 8, blocks.shape)]
+    blocks["color"] = rng.integers(0, 256, blocks.shape + (3,), dtype=np.uint8)
+    descs = np.zeros(len(ids), T.DESC_DTYPE)
+    descs["pos"] = ids
+
+    g = E.LauncherScene(hp)
+    o = O.OracleScene(hp, cp, rp, T.make_scene_options(offline=True, gc=True))
+    g.set_transform(pose, O.mat4_inverse(pose))
+    o.set_transform(pose)
+    g.reset_mutex()
+    g.stream_in(descs, blocks, T.LOCK_ENTRY)
+    assert o.stream_in(descs, blocks) == 0
+    frame = E.DepthFrame(cp, depth, color)
+    packed = DeviceBuffer(8 * W * H)
+    job = g.frame_job(frame, cp, packed_ptr=packed.ptr)
+    prev = -1
+    while True:  # alloc until the heap stops changing; every pass packs the frame as well
+        g.reset_mutex()
+        g.alloc_job(job)
+        cur = g.download(with_voxels=False)["heap_counter"]
+        if cur == prev:
+            break
+        prev = cur
+    prev = -1
+    while True:
+        o.reset_mutex()
+        o.alloc(depth, color)
+        cur = o.heap_free_count()
+        if cur == prev:
+            break
+        prev = cur
+    n = g.compactify(cp)
+    assert n == o.compactify() and 512 < n <= 2048, n  # 512 workgroups: the wave-per-block shape
+    canonical.assert_same_scene(g.state(), o.state(), "before the pass")
+    g.reset_mutex()
+    g.integrate_fused(frame, cp, 3, T.LOCK_ENTRY, packed.ptr)  # VH_FUSED_GC | VH_FUSED_STARVE
+    o.integrate_depth_map(depth, color)
+    o.starve()
+    o.gc_identify()
+    o.reset_mutex()
+    o.gc_free()
+    gs, os_ = g.state(), o.state()
+    canonical.assert_same_scene(gs, os_, "after the fused pass")
+    # the crafted values were really blended: most crafted voxels changed
+    assert gs["num_occupied"] > 100

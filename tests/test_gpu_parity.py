@@ -165,6 +165,20 @@ def test_exact_shortcuts(vh, voxel, buckets):
     assert mism[1] == 0, f"umod_fast differs from % on {mism[1]} operands"
 
 
+@pytest.mark.parametrize("seed", [1, 77, 990001])
+def test_refined_division_equals_ieee_division_in_the_certified_ranges(vh, seed):
+    """integrate_block_certified's division (one refined reciprocal, two residual corrections, packed) == `/` bit for
+    bit on 64 M pseudo-random operand pairs per range: the projection's (divisor 2^-20..2^20, |numerator| 2^-100..2^60
+    or zero) and the blend's (divisor 1..510, |numerator| 2^-100..2^90)"""
+    import ctypes as C
+    from voxelhashing_amd.lib import DeviceBuffer, check
+    buf = DeviceBuffer(8)
+    check(vh.vh_debug_check_refined_division(1 << 26, seed, buf.ptr, None), "check")
+    mism = buf.download(np.uint32)
+    assert mism[0] == 0, f"projection range: differs from IEEE division on {mism[0]} operand pairs"
+    assert mism[1] == 0, f"blend range: differs from IEEE division on {mism[1]} operand pairs"
+
+
 def general_poses(n, seed):
     """camera-to-world matrices with every rotation axis in play: the orbit pose, then roll / pitch / yaw of up to 25
     degrees about the camera's own axes and a shift of up to 20 cm (the orbit alone only ever turns about y)"""

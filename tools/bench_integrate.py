@@ -44,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     flags = 1 if a.gc else 0
     out = {}
-    for what, pk in (("packed", packed), ("unpacked", None)):
+    for what, pk in (("unpacked", None), ("packed", packed)):
         for _ in range(10):
             check(L.vh_integrate_fused(C.byref(hd), C.byref(hpp), C.byref(frame.data), C.byref(cp), flags, 12345, None, 0, pk, None), "integrate")
         torch.cuda.synchronize()
@@ -61,6 +61,21 @@ def main():
     st = scene.getState()
     if st[9]:
         out["wave0"] = dict(cycles=int(st[8]), realtime_ticks=int(st[9]), MHz=round(100.0 * st[8] / st[9], 1), rounds=int(st[10]), active_waves=int(st[11]))
+        # a -DVH_KNOCKOUT=9 build leaves every wave's {start, end, hw id, xcc} behind (the last launch's)
+        import numpy as np
+        ne = hpp.m_hashNumBuckets * T.HASH_BUCKET_SIZE
+        na = int(st[11])
+        raw = lib.download(hd.d_hashCompactified + 16 * (ne // 2), np.uint32, 12 * na).reshape(na, 12)
+        t0 = int(raw[:, 0].min())
+        start, end = (raw[:, 0] - t0) / 100.0, (raw[:, 1] - t0) / 100.0  # us
+        xcc = raw[:, 3] & 0xf
+        q = lambda a: [round(float(x), 2) for x in np.percentile(a, [0, 10, 50, 90, 100])]
+        out["waves"] = dict(start_us=q(start), end_us=q(end), life_us=q(end - start))
+        ph = (raw[:, 4:10].astype(np.int64) - t0) / 100.0
+        two = raw[:, 9] != 0
+        out["phases_two_block_waves"] = {k: q(v[two]) for k, v in dict(staged1=ph[:, 0] - start, voxels1=ph[:, 1] - ph[:, 0], compute1=ph[:, 2] - ph[:, 1],
+                                                                        staged2=ph[:, 3] - ph[:, 2], voxels2=ph[:, 4] - ph[:, 3], compute2=ph[:, 5] - ph[:, 4], rest=end - ph[:, 5]).items()}
+        np.save(os.path.join(ROOT, "gpurun_out", "wave_stamps.npy"), raw)
     print(json.dumps(dict(lib=os.path.basename(lib.LIB_PATH), blocks=n, **out)))
     scene.integrateFinish(frame, cp)
 

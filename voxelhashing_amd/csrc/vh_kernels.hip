@@ -429,10 +429,10 @@ VHD Vox integrate_voxel_packed(const VhHashParams& hp, const VhDepthCameraParams
 // lives on the device (no host round trip), so the grid is fixed and the kernel picks its shape from the count:
 //   * few blocks (count <= workgroups): one WORKGROUP per block, two x-adjacent voxels (16 B) per lane -- the frame is
 //     a latency chain (entry -> voxels -> gather -> table edit), and four waves per block keep it short;
-//   * many blocks: one WAVE per block (4 KB = four 16-byte loads per lane), A = ceil(count / r) waves taking r blocks
-//     each (r = ceil(count / 5120): at most five waves per SIMD, all with the same load; the active waves fill whole
-//     workgroups).  min |sdf| / max weight are a wave reduction (no LDS, no barrier); lane 0 edits the table; the
-//     block's screen footprint is staged in LDS (below).
+//   * many blocks: one WAVE per block (4 KB = four 16-byte loads per lane), at most 5120 waves (five per SIMD; the
+//     active waves fill whole workgroups) that draw further blocks off a ticket counter.  min |sdf| / max weight are a
+//     wave reduction (no LDS, no barrier); lane 0 edits the table; the block's screen footprint is staged in LDS and
+//     blocks whose corners pass a range certificate take the packed arithmetic of integrate_block_certified (below).
 // Load j of lane l of a wave that holds a whole block: voxels 128 j + 2 l and + 1, i.e. x = 2l mod 8 (+1),
 // y = (l / 4) mod 8, z = 2j + l / 32 (delinearizeVoxelIndex, DSC/VoxelUtilHashSDF.h:313-318).
 template <bool PACKED>
@@ -458,10 +458,142 @@ VHD void integrate_pair(const VhHashParams& hp, const VhDepthCameraParams& cp, c
     raw = make_uint4(a.x, a.y, c.x, c.y);
 }
 
+// ---- the voxel pair of a lane as a two-vector: packed fp32 instructions (v_pk_mul/add/fma_f32: two IEEE operations per
+// issue slot; each component is the scalar instruction's result)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+VHD f32x2 both(float v) { return (f32x2){ v, v }; }
+VHD f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// v_cvt_i32_f32 truncates, saturates and sends NaN to 0 by itself: f2i() without the v_trunc_f32 the compiler puts in front
+VHD int cvt_rz(float v)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// The reciprocal the compiler's own expansion of an fp32 division forms when v_div_scale_f32 leaves its operands alone:
+// v_rcp_f32 and one Newton step.
+VHD f32x2 rcp_refined2(f32x2 d)
+{
+    const f32x2 y0 = (f32x2){ __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
+    const f32x2 e = fma2(-d, y0, both(1.0f));
+    return fma2(e, y0, y0);
+}
+// n / d with y = rcp_refined2(d): the rest of that expansion (product, two residual corrections), instruction for
+// instruction, minus v_div_scale / v_div_fmas' scaling / v_div_fixup.  Those three only act when an operand is zero,
+// infinite, NaN or denormal, when |n| < 2^-103, when |d| >= 2^126 or when the exponents of n and d are 96 or more apart
+// (the ISA's v_div_scale_f32 cases); outside of that the result is the division's, bit for bit.  Callers guard the range.
+VHD f32x2 div_refined2(f32x2 n, f32x2 d, f32x2 y)
+{
+    f32x2 q = n * y;
+    f32x2 r = fma2(-d, q, n);
+    q = fma2(r, y, q);
+    r = fma2(-d, q, n);
+    return fma2(r, y, q);
+}
+
+// One block by one wave, the hot shape of the dense case: integrate_voxel_packed for the eight voxels of a lane (four
+// x-adjacent pairs) with ~60 instead of ~110 vector instructions per voxel.  Only for blocks the caller has certified:
+//   * the block's footprint is staged in LDS (tile, x0, y0, w, h);
+//   * at all eight CORNER voxels 2^-20 <= pf.z <= 2^20 and |pf.x fx|, |pf.y fy| <= 2^60.  Every voxel of the block then
+//     satisfies the same: each float operation of the transform is monotone in each of its operands, so pf.x, pf.y,
+//     pf.z and the two products, as computed, take their extremes over the block at corner voxels;
+//   * m_truncation > 0, m_truncScale >= 0 (so that a pixel that integrates has truncation > 0: the reference's
+//     two-sided clamp is then the median of {sdf, -truncation, truncation}).
+// What changes against the plain code, none of it in the results:
+//   * the two divisions by pf.z share one refined reciprocal (div_refined2; a numerator below 2^-60, where the
+//     argument above stops, gives a quotient below 2^-38 by either route, which the following "+ mx, + 0.5, truncate"
+//     cannot see);
+//   * the blend's division by the weight sum (1..510) takes the same route, with the exact division for any numerator
+//     outside [2^-100, 2^90) (never seen with voxels this library wrote; a crafted .hashgrid could hold one);
+//   * the pixel comes from the staged tile by an LDS read; a voxel that projects outside the staged box (not seen: the
+//     box is the hull of the corners' pixels and a margin) is gathered from the frame as before;
+//   * everything is written for the pair of a lane, so that the compiler can issue packed fp32.
+VHD void integrate_block_certified(const VhHashParams& hp, const VhDepthCameraParams& cp, const uint2* packed, const uint2* tile, uint32_t tileStride,
+                                   uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, int ex, int ey, int ez, uint32_t lane, uint32_t flags,
+                                   uint4 (&raw)[4], float& minSdf, uint32_t& maxW)
+{
+    const float vs = hp.m_virtualVoxelSize;
+    const float* m = hp.m_rigidTransformInverse;
+    const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
+    // vvp_to_world, mat_mul_p: ((m0 x + m1 y) + m2 z) + m3 per row; the first sum does not depend on z
+    const f32x2 xw = (f32x2){ (float)(ex * VH_SDF_BLOCK_SIZE + lx), (float)(ex * VH_SDF_BLOCK_SIZE + lx + 1) } * vs;
+    const float yw = (float)(ey * VH_SDF_BLOCK_SIZE + ly) * vs;
+    f32x2 ab[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) ab[r] = m[4 * r] * xw + both(m[4 * r + 1] * yw);
+    uint32_t maxCw = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float zw = (float)(ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0) * vs;
+        f32x2 pf[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) pf[r] = (ab[r] + both(m[4 * r + 2] * zw)) + both(m[4 * r + 3] * 1.0f);
+        // cameraToKinectScreenInt: int((pf.x fx / pf.z + mx) + 0.5f), likewise y
+        const f32x2 y = rcp_refined2(pf[2]);
+        const f32x2 fsx = (div_refined2(pf[0] * cp.fx, pf[2], y) + cp.mx) + 0.5f;
+        const f32x2 fsy = (div_refined2(pf[1] * cp.fy, pf[2], y) + cp.my) + 0.5f;
+        uint2 px[2]; // the pixel of each voxel; weight byte 0: nothing to integrate (pack_pixel), or no pixel at all
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t sx = (uint32_t)cvt_rz(fsx[k]), sy = (uint32_t)cvt_rz(fsy[k]);
+            const uint32_t tx = sx - x0, ty = sy - y0; // unsigned: a pixel left of / above the box wraps to a huge number
+            const bool inBox = (tx < w) & (ty < h);    // the box lies inside the image
+            // (one ballot per comparison: the ballot of their conjunction goes through a register and back)
+            const bool allInBox = (__builtin_amdgcn_ballot_w64(tx < w) & __builtin_amdgcn_ballot_w64(ty < h)) == ~0ull; // (every lane is active here)
+            // (as one indivisible 8-byte read: left alone the compiler splits it in two)
+            // (no clamp of the index: an LDS read beyond the workgroup's allocation returns zero, one inside it some other
+            // pixel, and the weight byte of a voxel outside the box is cleared below either way)
+            const unsigned long long t = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&tile[__umul24(ty, tileStride) + tx]),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            px[k] = make_uint2((uint32_t)t, inBox ? (uint32_t)(t >> 32) : 0u);
+            if (__builtin_expect(!allInBox, 0)) {
+                if (!inBox && sx < cp.m_imageWidth && sy < cp.m_imageHeight) px[k] = packed[sy * cp.m_imageWidth + sx];
+            }
+        }
+        // integrateDepthMapKernel :447-472 and combineVoxel :229-250 (apply_pixel / combine_voxel above) for the pair
+        const Vox s0 = unpack_vox(make_uint2(raw[j].x, raw[j].y)), s1 = unpack_vox(make_uint2(raw[j].z, raw[j].w));
+        const f32x2 depth = (f32x2){ __uint_as_float(px[0].x), __uint_as_float(px[1].x) };
+        const f32x2 sdf = depth - pf[2];
+        const f32x2 truncation = both(hp.m_truncation) + hp.m_truncScale * depth;
+        const bool use0 = ((px[0].y >> 24) != 0u) & (sdf.x > -truncation.x);
+        const bool use1 = ((px[1].y >> 24) != 0u) & (sdf.y > -truncation.y);
+        const f32x2 clamped = (f32x2){ __builtin_amdgcn_fmed3f(sdf.x, -truncation.x, truncation.x), __builtin_amdgcn_fmed3f(sdf.y, -truncation.y, truncation.y) };
+        const f32x2 wOld = (f32x2){ (float)(s0.cw >> 24), (float)(s1.cw >> 24) }, wNew = (f32x2){ (float)(px[0].y >> 24), (float)(px[1].y >> 24) };
+        const f32x2 num = (f32x2){ s0.sdf, s1.sdf } * wOld + clamped * wNew;
+        const f32x2 den = wOld + wNew; // exact: integers up to 510
+        f32x2 q = div_refined2(num, den, rcp_refined2(den));
+        const bool odd0 = use0 & !((fabsf(num.x) >= 0x1p-100f) & (fabsf(num.x) < 0x1p90f));
+        const bool odd1 = use1 & !((fabsf(num.y) >= 0x1p-100f) & (fabsf(num.y) < 0x1p90f));
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd0 | odd1) != 0ull, 0)) {
+            if (odd0) q.x = num.x / den.x;
+            if (odd1) q.y = num.y / den.y;
+        }
+        Vox v[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const Vox st = k ? s1 : s0;
+            // colour: the byte-wise average rounded up (combine_voxel) is v_lerp_u8 with the rounding bit set; the weight
+            // byte comes in by v_perm_b32 (the top byte of the average is not used)
+            const uint32_t rgb = __builtin_amdgcn_lerp(st.cw, px[k].y, 0x01010101u);
+            const uint32_t wSum = min(hp.m_integrationWeightMax, (st.cw >> 24) + (px[k].y >> 24));
+            const bool use = k ? use1 : use0;
+            v[k].sdf = use ? q[k] : st.sdf;
+            v[k].cw = use ? __builtin_amdgcn_perm(wSum, rgb, 0x04020100u) : st.cw;
+        }
+        if (flags & VH_FUSED_STARVE) { v[0] = starve_voxel(v[0]); v[1] = starve_voxel(v[1]); }
+        minSdf = fminf(minSdf, fminf(gc_key(v[0]), gc_key(v[1])));
+        maxCw = max(maxCw, max(v[0].cw, v[1].cw)); // the weight is the top byte: the largest word has the largest weight
+        const uint2 a = pack_vox(v[0]), c = pack_vox(v[1]);
+        raw[j] = make_uint4(a.x, a.y, c.x, c.y);
+    }
+    maxW = max(maxW, maxCw >> 24);
+}
+
 constexpr uint32_t kIntegrateWavesMost = 5120; // waves that take blocks when there are many: five per SIMD
-constexpr uint32_t kIntegrateTile = 32;        // a block's screen footprint of up to 32 x 30 pixels is staged in LDS,
-constexpr uint32_t kIntegrateTileRows = 30;    // rows 34 pixels apart (272 B: vertical neighbours fall into different banks):
-constexpr uint32_t kIntegrateTileStride = 34;  // just under 32 KB per workgroup, five workgroups per compute unit
+constexpr uint32_t kIntegrateTile = 32;        // a block's screen footprint of up to 32 x 29 pixels is staged in LDS,
+constexpr uint32_t kIntegrateTileRows = 29;    // rows 34 pixels apart (272 B: vertical neighbours fall into different banks):
+constexpr uint32_t kIntegrateTileStride = 34;  // 31.6 KB per workgroup = 25 allocation units of 1280 B, five workgroups per compute
+                                               // unit (30 rows are 26 units: per-wave time stamps showed four resident, the fifth waiting)
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, VhDepthCameraParams cp,
@@ -525,12 +657,16 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
         return;
     }
 
-    // ---- one wave per block, `rounds` blocks per wave
-    const uint32_t rounds = (count + kIntegrateWavesMost - 1u) / kIntegrateWavesMost;
-    const uint32_t nActive = (count + rounds - 1u) / rounds; // <= kIntegrateWavesMost <= the waves of the grid
+    // ---- one wave per block: the first min(count, 5120) waves (five per SIMD; the hardware deals workgroups to the
+    // compute units evenly) take blocks w, w + 5120, ...: no SIMD gets more than a block or two above the mean.
+    // Measured and dropped: ceil(count / rounds) waves with `rounds` blocks each (SIMDs with five waves finished 3 us
+    // after those with four: 27 us for 8 600 blocks), and a ticket counter (agent-scope atomics on one address are
+    // served at the memory side of the eight L2s, ~12 ns each: 165 us).
+    const uint32_t nActive = min(min(count, kIntegrateWavesMost), gridDim.x * (256u / kWave));
     if (wFirst >= nActive) return;
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9 // measurement build: shader clock over one wave's lifetime
     const uint64_t stampC0 = __builtin_amdgcn_s_memtime(), stampR0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t stamps[6] = { 0u, 0u, 0u, 0u, 0u, 0u }, stampN = 0u; // per block: staged, voxels arrived, computed (two blocks)
 #endif
     const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
     uint32_t b = wFirst;
@@ -564,12 +700,19 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
             // box all the same is gathered from the frame itself: the box decides where a pixel is read, never which.
             int cx, cy;
             float cz;
+            bool cornerFine;
             {
                 const uint32_t c = lane & 7u;
                 const I3 pc = mki3(ex * VH_SDF_BLOCK_SIZE + ((c & 1u) ? 7 : 0), ey * VH_SDF_BLOCK_SIZE + ((c & 2u) ? 7 : 0), ez * VH_SDF_BLOCK_SIZE + ((c & 4u) ? 7 : 0));
-                uint32_t ux, uy;
-                (void)project_voxel(hp, cp, pc, ux, uy, cz);
-                cx = (int)ux; cy = (int)uy;
+                // where the corner lands, to within a pixel or so (a hardware reciprocal instead of two divisions: the box
+                // only decides where a pixel is read from; the conversion saturates and sends NaN to 0)
+                const F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pc));
+                const float rz = __builtin_amdgcn_rcpf(pf.z);
+                cx = cvt_rz((pf.x * cp.fx * rz + cp.mx) + 0.5f);
+                cy = cvt_rz((pf.y * cp.fy * rz + cp.my) + 0.5f);
+                cz = pf.z;
+                // the certificate of integrate_block_certified (each lane holds one of the eight corners)
+                cornerFine = pf.z >= 0x1p-20f && pf.z <= 0x1p20f && fabsf(pf.x * cp.fx) <= 0x1p60f && fabsf(pf.y * cp.fy) <= 0x1p60f;
             }
             int bx0 = cx, bx1 = cx, by0 = cy, by1 = cy;
 #pragma unroll
@@ -605,6 +748,23 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+#if !defined(VH_INTEGRATE_PLAIN) // (measurement / test builds: every block through the plain code)
+            const bool certified = staged && __builtin_amdgcn_ballot_w64(!cornerFine) == 0ull && hp.m_truncation > 0.0f && hp.m_truncScale >= 0.0f;
+#else
+            const bool certified = false;
+#endif
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9
+            if (stampN < 6u) stamps[stampN++] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // staged
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (stampN < 6u) stamps[stampN++] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // voxels here
+#endif
+            if (certified) {
+                integrate_block_certified(hp, cp, packed, tile, kIntegrateTileStride, x0, y0, w, h, ex, ey, ez, lane, flags, raw, minSdf, maxW);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9
+                asm volatile("" : "+v"(raw[3].x), "+v"(raw[0].x));
+                if (stampN < 6u) stamps[stampN++] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // computed
+#endif
+            } else
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 Vox v[2] = { unpack_vox(make_uint2(raw[j].x, raw[j].y)), unpack_vox(make_uint2(raw[j].z, raw[j].w)) };
@@ -663,7 +823,14 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9
     if (wFirst == 0u && lane == 0u) {
         const uint64_t c = __builtin_amdgcn_s_memtime() - stampC0, r = __builtin_amdgcn_s_memrealtime() - stampR0;
-        hd.d_state[8] = (uint32_t)c; hd.d_state[9] = (uint32_t)r; hd.d_state[10] = rounds; hd.d_state[11] = nActive;
+        hd.d_state[8] = (uint32_t)c; hd.d_state[9] = (uint32_t)r; hd.d_state[10] = (count + nActive - 1u) / nActive; hd.d_state[11] = nActive;
+    }
+    if (lane == 0u) { // every wave's life in the unused upper half of the compactified list: {start, end (100 MHz ticks), hardware id, xcc id}
+        const uint32_t hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        reinterpret_cast<uint4*>(hd.d_hashCompactified)[nEntries / 2u + 3u * wFirst] =
+            make_uint4((uint32_t)stampR0, (uint32_t)__builtin_amdgcn_s_memrealtime(), hwid, xcc);
+        reinterpret_cast<uint4*>(hd.d_hashCompactified)[nEntries / 2u + 3u * wFirst + 1u] = make_uint4(stamps[0], stamps[1], stamps[2], stamps[3]);
+        reinterpret_cast<uint4*>(hd.d_hashCompactified)[nEntries / 2u + 3u * wFirst + 2u] = make_uint4(stamps[4], stamps[5], 0u, 0u);
     }
 #endif
 }
@@ -2850,6 +3017,34 @@ __global__ __launch_bounds__(256) void k_check_fast_math(float b, HashMod hm, ui
     }
 }
 
+// checks div_refined2 (integrate_block_certified's division) against `/` inside the ranges its callers certify:
+// [0] the projection: divisor in [2^-20, 2^20], |numerator| in [2^-100, 2^60] or zero; [1] the blend: divisor an integer
+// in 1..510, |numerator| in [2^-100, 2^90)
+__global__ __launch_bounds__(256) void k_check_refined_division(uint32_t n, uint32_t seed, uint32_t* mismatches)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = (i + 1u) * 2654435761u ^ seed;
+    s ^= s >> 15; s *= 2246822519u; s ^= s >> 13; s *= 3266489917u; s ^= s >> 16;
+    const uint32_t u = s * 747796405u + 2891336453u, t = u * 2654435761u + 40503u;
+    // sign and mantissa from the random words, exponents spread evenly over the certified ranges
+    const uint32_t dExp = 127u - 20u + (s >> 8) % 41u, nExpP = 127u - 100u + (u >> 8) % 161u, nExpB = 127u - 100u + (t >> 8) % 190u;
+    float d = __uint_as_float((dExp << 23) | (s & 0x7fffffu));
+    if (dExp == 127u + 20u) d = 0x1p20f; // the closed end of the range
+    float nP = __uint_as_float((u & 0x80000000u) | (nExpP << 23) | (u & 0x7fffffu));
+    if (nExpP == 127u + 60u) nP = copysignf(0x1p60f, nP);
+    if ((i & 1023u) == 0u) nP = (i & 1024u) ? 0.0f : -0.0f;
+    if ((i & 1023u) == 1u) { d = 1.0f + (float)(i >> 10) * 0x1p-23f; nP = __uint_as_float(0x3fffffffu - (s & 0xffu)); } // mantissas near all-ones
+    const float dB = (float)(1u + (s >> 3) % 510u);
+    const float nB = __uint_as_float((t & 0x80000000u) | (nExpB << 23) | (t & 0x7fffffu));
+    const f32x2 dd = (f32x2){ d, dB }, nn = (f32x2){ nP, nB };
+    const f32x2 q = div_refined2(nn, dd, rcp_refined2(dd));
+    const float wantP = nP / d, wantB = nB / dB;
+    // (a zero numerator: the projection takes either zero -- "+ mx, + 0.5" cannot tell them apart)
+    if (__float_as_uint(q.x) != __float_as_uint(wantP) && !(wantP == 0.0f && q.x == 0.0f)) atomicAdd(&mismatches[0], 1u);
+    if (__float_as_uint(q.y) != __float_as_uint(wantB)) atomicAdd(&mismatches[1], 1u);
+}
+
 inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // multiply-shift constants of umod_fast for divisor d >= 2
@@ -3392,6 +3587,15 @@ int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_
     if (!hd || !hp || !d_ops || !d_results) return VH_ERR_BAD_ARGUMENT;
     if (n == 0) return VH_OK;
     k_debug_hash_ops<<<1, 64, 0, (hipStream_t)stream>>>(*hd, *hp, d_ops, d_results, n);
+    return vh_last_launch_error();
+}
+
+int vh_debug_check_refined_division(uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream)
+{
+    if (!d_mismatches) return VH_ERR_BAD_ARGUMENT;
+    VH_HIP(hipMemsetAsync(d_mismatches, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
+    if (n == 0) return VH_OK;
+    k_check_refined_division<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(n, seed, d_mismatches);
     return vh_last_launch_error();
 }
 
