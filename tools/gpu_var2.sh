@@ -1,15 +1,18 @@
 #!/bin/bash
+# the shipped library and every scratch/lib_*.so variant through the bench on one box (twice, interleaved)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/var2
+O=gpurun_out/${1:-var3}
+CFGS=${2:-cfg2}
 mkdir -p $O
-for cfg in cfg2 cfg3 cfg4; do
+for rep in 1 2; do
+for cfg in $CFGS; do
 for k in "" $(ls scratch/lib_*.so 2>/dev/null); do
   n=$(basename "${k:-shipped}" .so)
   export VH_LIB_PATH=${k:+$PWD/$k}
   [ -z "$k" ] && unset VH_LIB_PATH
-  timeout -k 10 300 python bench.py --config $cfg --no-streaming --steps 200 --warmup 40 --no-cpu-baseline --no-extra-legs > $O/$cfg.$n.json 2> $O/$cfg.$n.err
-  python - "$O/$cfg.$n.json" "$cfg $n" <<'PY'
+  timeout -k 10 300 python bench.py --config $cfg --no-streaming --steps 300 --warmup 50 --no-cpu-baseline --no-extra-legs > $O/$cfg.$n.$rep.json 2> $O/$cfg.$n.$rep.err
+  python - "$O/$cfg.$n.$rep.json" "$cfg $n" <<'PY'
 import json,sys
 try:
     j=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
@@ -17,5 +20,6 @@ try:
 except Exception as e:
     print(sys.argv[2], "failed", e)
 PY
+done
 done
 done

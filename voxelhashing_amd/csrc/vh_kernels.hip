@@ -209,10 +209,98 @@ __global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, V
 // prefix and ONE atomic per wave.
 // ---------------------------------------------------------------------------
 
-// one lane per word of 32 occupancy bits (whole waves take part: ballots inside)
-VHD void compactify_words(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, uint32_t wordIdx)
+// v_cvt_i32_f32 truncates, saturates and sends NaN to 0 by itself: f2i() without the v_trunc_f32 the compiler puts in front
+VHD int cvt_rz(float v)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+constexpr uint32_t kIntegrateTile = 32;        // a block's screen footprint of up to 32 x 29 pixels is staged in LDS,
+constexpr uint32_t kIntegrateTileRows = 29;    // rows 34 pixels apart (272 B: vertical neighbours fall into different banks):
+constexpr uint32_t kIntegrateTileStride = 34;  // 31.6 KB per workgroup = 25 allocation units of 1280 B, five workgroups per compute
+                                               // unit (30 rows are 26 units: per-wave time stamps showed four resident, the fifth waiting)
+
+
+// What the fused integrate pass wants to know of a block before it touches a voxel, worked out once per block by the
+// compactify pass (one lane per block there; in the integrate pass it would be ~160 instructions of every wave) and
+// kept in the three spare words of the block's entry in the compactified list:
+//   box: the block's screen footprint for the frame being integrated -- the hull of its eight corner voxels' pixels, one
+//     pixel wider all round (a perspective projection maps the block into the hull of its corners when all of them lie
+//     in front of the camera; the extra pixel covers rounding), clipped to the image, starting at an even pixel.  The
+//     corners are projected with a hardware reciprocal: the box only decides WHERE a pixel is read from (the tile
+//     staged in LDS or the frame itself), never which pixel;
+//   VH_BOX_STAGED: the box is worth staging (in front of the camera, at most 32 x 29 pixels, even image width);
+//   VH_BOX_CERTIFIED: the range certificate of integrate_block_certified holds at all eight corners (exact arithmetic,
+//     the same expressions the voxels go through);
+//   tag: which transform / camera / voxel size that was worked out for.  A pass that runs with another one works it
+//     out again itself.
+constexpr uint32_t VH_BOX_STAGED = 1u, VH_BOX_CERTIFIED = 2u;
+struct BlockBox {
+    uint32_t x0, y0, w, h, flags;
+};
+VHD uint32_t frame_tag(const VhHashParams& hp, const VhDepthCameraParams& cp)
+{
+    uint32_t t = 0x9E3779B9u;
+#pragma unroll
+    for (int i = 0; i < 12; i++) t = (t ^ __float_as_uint(hp.m_rigidTransformInverse[i])) * 0x01000193u + (t >> 15);
+    const uint32_t more[7] = { __float_as_uint(hp.m_virtualVoxelSize), __float_as_uint(cp.fx), __float_as_uint(cp.fy), __float_as_uint(cp.mx),
+                               __float_as_uint(cp.my), cp.m_imageWidth, cp.m_imageHeight };
+#pragma unroll
+    for (int i = 0; i < 7; i++) t = (t ^ more[i]) * 0x01000193u + (t >> 15);
+    return t | 1u; // never 0: a zeroed entry carries no box
+}
+VHD BlockBox block_box(const VhHashParams& hp, const VhDepthCameraParams& cp, int ex, int ey, int ez)
+{
+    int bx0 = 0x7fffffff, bx1 = (int)0x80000000, by0 = 0x7fffffff, by1 = (int)0x80000000;
+    float cz = pinf();
+    bool fine = true;
+#pragma unroll
+    for (uint32_t c = 0; c < 8u; c++) {
+        const I3 pc = mki3(ex * VH_SDF_BLOCK_SIZE + ((c & 1u) ? 7 : 0), ey * VH_SDF_BLOCK_SIZE + ((c & 2u) ? 7 : 0), ez * VH_SDF_BLOCK_SIZE + ((c & 4u) ? 7 : 0));
+        const F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pc));
+        const float rz = __builtin_amdgcn_rcpf(pf.z);
+        const int cx = cvt_rz((pf.x * cp.fx * rz + cp.mx) + 0.5f), cy = cvt_rz((pf.y * cp.fy * rz + cp.my) + 0.5f); // (saturating; NaN -> 0)
+        bx0 = min(bx0, cx); bx1 = max(bx1, cx);
+        by0 = min(by0, cy); by1 = max(by1, cy);
+        cz = fminf(cz, pf.z);
+        fine = fine && pf.z >= 0x1p-20f && pf.z <= 0x1p20f && fabsf(pf.x * cp.fx) <= 0x1p60f && fabsf(pf.y * cp.fy) <= 0x1p60f;
+    }
+    const bool inFront = cz > 1e-3f;
+    // (coordinates beyond +-2^30 would overflow the arithmetic below: such a block is simply not staged)
+    const bool sane = bx0 > -(1 << 30) && bx1 < (1 << 30) && by0 > -(1 << 30) && by1 < (1 << 30);
+    const int x0i = max(bx0 - 1, 0) & ~1, x1i = min(bx1 + 1, (int)cp.m_imageWidth - 1);
+    const int y0i = max(by0 - 1, 0), y1i = min(by1 + 1, (int)cp.m_imageHeight - 1);
+    const bool staged = inFront && sane && x0i <= x1i && y0i <= y1i && (x1i - x0i) < (int)kIntegrateTile && (y1i - y0i) < (int)kIntegrateTileRows &&
+                        (cp.m_imageWidth & 1u) == 0u && cp.m_imageWidth <= 0xffffu && cp.m_imageHeight <= 0xffffu;
+    BlockBox b;
+    b.x0 = staged ? (uint32_t)x0i : 0u;
+    b.y0 = staged ? (uint32_t)y0i : 0u;
+    b.w = staged ? (uint32_t)(x1i - x0i + 1) : 0u;
+    b.h = staged ? (uint32_t)(y1i - y0i + 1) : 0u;
+    b.flags = (staged ? VH_BOX_STAGED : 0u) | (fine ? VH_BOX_CERTIFIED : 0u);
+    return b;
+}
+// the spare words of a compactified entry: {x0 | y0 << 16, w | h << 8 | flags << 16, tag}
+VHD uint4 pack_box(uint32_t offset, const BlockBox& b, uint32_t tag) { return make_uint4(offset, b.x0 | (b.y0 << 16), b.w | (b.h << 8) | (b.flags << 16), tag); }
+
+// One lane per word of 32 occupancy bits; what a workgroup keeps is queued in LDS and appended to the list with ONE
+// atomic per workgroup (agent-scope atomics on one address are served one after the other at the memory side of the
+// eight L2s, ~12 ns each: with one per wave and slot the dense scene's 8 700 blocks cost 40 us).  The queued entries
+// then get their boxes, one lane each.  Entries beyond the queue's capacity take the list directly.
+constexpr uint32_t kCompactQueue = 768;
+struct CompactShared {
+    int4 q[kCompactQueue];
+    uint32_t off[kCompactQueue];
+    uint32_t n, base;
+};
+__device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, uint32_t wordIdx, CompactShared& sh)
 {
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
+    const uint32_t tag = frame_tag(hp, cp);
+    if (threadIdx.x == 0) sh.n = 0u;
+    __syncthreads();
     uint32_t bits = (wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
     while (__any(bits != 0u)) {
         const bool has = bits != 0u;
@@ -232,27 +320,38 @@ VHD void compactify_words(const VhHashData& hd, const VhHashParams& hp, const Vh
 #pragma unroll
         for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
             const int4 q = qs[j];
-            const uint32_t off = offs[j];
             const bool keep = has && q.w != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(q.x, q.y, q.z));
-            const uint64_t m = __ballot(keep);
-            if (m) {
-                uint32_t base = 0;
-                if (lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1))
-                    base = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)__popcll(m));
-                base = __builtin_amdgcn_readlane(base, __ffsll((unsigned long long)m) - 1);
-                if (keep) {
-                    VhHashEntry* o = &hd.d_hashCompactified[base + (uint32_t)__popcll(m & lanemask_lt())];
-                    o->offset = off;
+            if (keep) {
+                const uint32_t at = atomicAdd(&sh.n, 1u);
+                if (at < kCompactQueue) {
+                    sh.q[at] = q;
+                    sh.off[at] = offs[j];
+                } else { // the queue is full: straight to the list
+                    VhHashEntry* o = &hd.d_hashCompactified[(uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, 1)];
+                    *(reinterpret_cast<uint4*>(o) + 1) = pack_box(offs[j], block_box(hp, cp, q.x, q.y, q.z), tag);
                     store_quad(o, q);
                 }
             }
         }
     }
+    __syncthreads();
+    const uint32_t n = min(sh.n, kCompactQueue);
+    if (n == 0u) return; // (the same for every thread)
+    if (threadIdx.x == 0) sh.base = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)n);
+    __syncthreads();
+    const uint32_t base = sh.base;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int4 q = sh.q[i];
+        VhHashEntry* o = &hd.d_hashCompactified[base + i];
+        *(reinterpret_cast<uint4*>(o) + 1) = pack_box(sh.off[i], block_box(hp, cp, q.x, q.y, q.z), tag);
+        store_quad(o, q);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp)
 {
-    compactify_words(hd, hp, cp, blockIdx.x * blockDim.x + threadIdx.x);
+    __shared__ CompactShared sh;
+    compactify_group(hd, hp, cp, blockIdx.x * blockDim.x + threadIdx.x, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -463,13 +562,6 @@ VHD void integrate_pair(const VhHashParams& hp, const VhDepthCameraParams& cp, c
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 VHD f32x2 both(float v) { return (f32x2){ v, v }; }
 VHD f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-// v_cvt_i32_f32 truncates, saturates and sends NaN to 0 by itself: f2i() without the v_trunc_f32 the compiler puts in front
-VHD int cvt_rz(float v)
-{
-    int r;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
 // The reciprocal the compiler's own expansion of an fp32 division forms when v_div_scale_f32 leaves its operands alone:
 // v_rcp_f32 and one Newton step.
 VHD f32x2 rcp_refined2(f32x2 d)
@@ -590,13 +682,9 @@ VHD void integrate_block_certified(const VhHashParams& hp, const VhDepthCameraPa
 }
 
 constexpr uint32_t kIntegrateWavesMost = 5120; // waves that take blocks when there are many: five per SIMD
-constexpr uint32_t kIntegrateTile = 32;        // a block's screen footprint of up to 32 x 29 pixels is staged in LDS,
-constexpr uint32_t kIntegrateTileRows = 29;    // rows 34 pixels apart (272 B: vertical neighbours fall into different banks):
-constexpr uint32_t kIntegrateTileStride = 34;  // 31.6 KB per workgroup = 25 allocation units of 1280 B, five workgroups per compute
-                                               // unit (30 rows are 26 units: per-wave time stamps showed four resident, the fifth waiting)
-
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, VhDepthCameraParams cp,
+__global__ __launch_bounds__(256) // WAVES_ATTR
+void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, VhDepthCameraParams cp,
                                                          uint32_t flags, int32_t lockToken, uint32_t* countMirror, uint32_t mirrorTag,
                                                          const uint2* packed)
 {
@@ -614,8 +702,12 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
     // once and free their slot: a workgroup's LDS and registers are held until its last wave is done)
     const uint32_t wFirst = blockIdx.x * (256u / kWave) + wave;
     int4 qg = make_int4(0, 0, 0, 0), qw = make_int4(0, 0, 0, 0);
+    uint4 boxw = make_uint4(0u, 0u, 0u, 0u); // the entry's second half: {offset, box, box, tag} (compactify_group)
     if (blockIdx.x < nEntries) qg = load_quad(&hd.d_hashCompactified[blockIdx.x]);
-    if (wFirst < nEntries) qw = load_quad(&hd.d_hashCompactified[wFirst]);
+    if (wFirst < nEntries) {
+        qw = load_quad(&hd.d_hashCompactified[wFirst]);
+        if (PACKED) boxw = *(reinterpret_cast<const uint4*>(&hd.d_hashCompactified[wFirst]) + 1);
+    }
     // host-visible copy of the block count and the caller's tag (mapped pinned memory): replaces a per-frame
     // device->host copy, and lets the host see how far the device has come
     if (countMirror && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint2*>(countMirror) = make_uint2(count, mirrorTag);
@@ -668,17 +760,26 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
     const uint64_t stampC0 = __builtin_amdgcn_s_memtime(), stampR0 = __builtin_amdgcn_s_memrealtime();
     uint32_t stamps[6] = { 0u, 0u, 0u, 0u, 0u, 0u }, stampN = 0u; // per block: staged, voxels arrived, computed (two blocks)
 #endif
-    const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
     uint32_t b = wFirst;
     int4 q = qw;
+    uint4 qbox = boxw;
     uint2* tile = sTile[wave];
+    const uint32_t tagNow = frame_tag(hp, cp);
     for (;;) {
+        // What depends on the lane alone is formed again for every block (a dozen cheap instructions): hoisted out of the
+        // loop it is a dozen registers that live through everything, and the compiler parks them in scratch memory.
+        uint32_t lane = lane_id();
+        asm volatile("" : "+v"(lane));
+        const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
         const int ex = __builtin_amdgcn_readfirstlane(q.x), ey = __builtin_amdgcn_readfirstlane(q.y);
         const int ez = __builtin_amdgcn_readfirstlane(q.z), ptr = __builtin_amdgcn_readfirstlane(q.w);
         uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + lane;
         uint4 raw[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) raw[j] = vp[j * kWave];
+        if (PACKED) qbox = *(reinterpret_cast<const uint4*>(&hd.d_hashCompactified[b]) + 1);
+        const uint32_t boxA = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbox.y), boxB = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbox.z);
+        const uint32_t boxTag = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbox.w);
         const bool hasNext = b + nActive < count;
         if (hasNext) q = load_quad(&hd.d_hashCompactified[b + nActive]); // the next block's entry behind this block's voxels
         // (Requesting the next block's voxels here as well was measured: slower.  The waves do not wait for the stream --
@@ -686,6 +787,7 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
 
         float minSdf = pinf();
         uint32_t maxW = 0u;
+        bool wrote = false; // the plain code has put the block back itself
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 1 // measurement build: the voxel stream alone (read, write back)
         if (false) {
 #else
@@ -694,45 +796,19 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
             // A voxel's gather from the frame is one cache access per LANE -- 64 tag look-ups per wave instruction, the
             // bound of this shape before staging (1 cm voxels: 13 us of a 33 us launch).  So the block's screen
             // footprint is staged in LDS first, four image rows per load instruction (whole lines), while the voxel
-            // loads are in flight: the box of the eight corner voxels' pixels, one pixel wider all round (a perspective
-            // projection maps the block into the hull of its corners when all of them lie in front of the camera; the
-            // extra pixel covers the rounding of the per-voxel arithmetic).  A voxel that projects outside the staged
-            // box all the same is gathered from the frame itself: the box decides where a pixel is read, never which.
-            int cx, cy;
-            float cz;
-            bool cornerFine;
-            {
-                const uint32_t c = lane & 7u;
-                const I3 pc = mki3(ex * VH_SDF_BLOCK_SIZE + ((c & 1u) ? 7 : 0), ey * VH_SDF_BLOCK_SIZE + ((c & 2u) ? 7 : 0), ez * VH_SDF_BLOCK_SIZE + ((c & 4u) ? 7 : 0));
-                // where the corner lands, to within a pixel or so (a hardware reciprocal instead of two divisions: the box
-                // only decides where a pixel is read from; the conversion saturates and sends NaN to 0)
-                const F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pc));
-                const float rz = __builtin_amdgcn_rcpf(pf.z);
-                cx = cvt_rz((pf.x * cp.fx * rz + cp.mx) + 0.5f);
-                cy = cvt_rz((pf.y * cp.fy * rz + cp.my) + 0.5f);
-                cz = pf.z;
-                // the certificate of integrate_block_certified (each lane holds one of the eight corners)
-                cornerFine = pf.z >= 0x1p-20f && pf.z <= 0x1p20f && fabsf(pf.x * cp.fx) <= 0x1p60f && fabsf(pf.y * cp.fy) <= 0x1p60f;
-            }
-            int bx0 = cx, bx1 = cx, by0 = cy, by1 = cy;
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                bx0 = min(bx0, __shfl_xor(bx0, o)); bx1 = max(bx1, __shfl_xor(bx1, o));
-                by0 = min(by0, __shfl_xor(by0, o)); by1 = max(by1, __shfl_xor(by1, o));
-                cz = fminf(cz, __shfl_xor(cz, o));
-            }
-            bx0 = __builtin_amdgcn_readfirstlane(bx0); bx1 = __builtin_amdgcn_readfirstlane(bx1);
-            by0 = __builtin_amdgcn_readfirstlane(by0); by1 = __builtin_amdgcn_readfirstlane(by1);
-            const bool inFront = __builtin_amdgcn_readfirstlane(cz > 1e-3f ? 1 : 0) != 0;
-            // one pixel of margin, clipped to the image (coordinates beyond +-2^30 would overflow the arithmetic below:
-            // such a block is simply not staged); the box starts at an even pixel: rows are staged two pixels per lane
-            const bool sane = bx0 > -(1 << 30) && bx1 < (1 << 30) && by0 > -(1 << 30) && by1 < (1 << 30);
-            const int x0i = max(bx0 - 1, 0) & ~1, x1i = min(bx1 + 1, (int)cp.m_imageWidth - 1);
-            const int y0i = max(by0 - 1, 0), y1i = min(by1 + 1, (int)cp.m_imageHeight - 1);
-            const bool staged = inFront && sane && x0i <= x1i && y0i <= y1i && (x1i - x0i) < (int)kIntegrateTile && (y1i - y0i) < (int)kIntegrateTileRows &&
-                                (cp.m_imageWidth & 1u) == 0u;
-            const uint32_t x0 = (uint32_t)x0i, y0 = (uint32_t)y0i;
-            const uint32_t w = staged ? (uint32_t)(x1i - x0i + 1) : 0u, h = staged ? (uint32_t)(y1i - y0i + 1) : 0u;
+            // loads are in flight.  The box comes with the block's entry (block_box, worked out by the compactify pass
+            // for this very transform: the tag says so; a list made for another one goes through the plain code, every
+            // voxel gathered from the frame).  A voxel that projects outside the staged box all the same is gathered
+            // from the frame itself: the box decides where a pixel is read, never which.
+            BlockBox bb;
+            bb.x0 = boxA & 0xffffu; bb.y0 = boxA >> 16;
+            bb.w = boxB & 0xffu; bb.h = (boxB >> 8) & 0xffu;
+            bb.flags = boxTag == tagNow ? boxB >> 16 : 0u; // a box made for another transform: neither staged nor certified
+            // (a box that does not fit this image -- it cannot come from block_box for this frame -- is not used)
+            const bool staged = (bb.flags & VH_BOX_STAGED) != 0u && bb.w <= kIntegrateTile && bb.h <= kIntegrateTileRows && (bb.x0 & 1u) == 0u &&
+                                bb.x0 + bb.w <= cp.m_imageWidth && bb.y0 + bb.h <= cp.m_imageHeight && (cp.m_imageWidth & 1u) == 0u;
+            const uint32_t x0 = bb.x0, y0 = bb.y0;
+            const uint32_t w = staged ? bb.w : 0u, h = staged ? bb.h : 0u;
             if (staged) {
                 // lane -> (row r + lane / 16, pixels 2 (lane % 16) and + 1): four rows per load instruction.  An even image
                 // width and an even x0 keep a pixel pair inside its row.
@@ -749,7 +825,7 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
 #if !defined(VH_INTEGRATE_PLAIN) // (measurement / test builds: every block through the plain code)
-            const bool certified = staged && __builtin_amdgcn_ballot_w64(!cornerFine) == 0ull && hp.m_truncation > 0.0f && hp.m_truncScale >= 0.0f;
+            const bool certified = staged && (bb.flags & VH_BOX_CERTIFIED) != 0u && hp.m_truncation > 0.0f && hp.m_truncScale >= 0.0f;
 #else
             const bool certified = false;
 #endif
@@ -758,39 +834,46 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (stampN < 6u) stamps[stampN++] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // voxels here
 #endif
-            if (certified) {
+            if (__builtin_amdgcn_readfirstlane(certified ? 1 : 0) != 0) {
                 integrate_block_certified(hp, cp, packed, tile, kIntegrateTileStride, x0, y0, w, h, ex, ey, ez, lane, flags, raw, minSdf, maxW);
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9
                 asm volatile("" : "+v"(raw[3].x), "+v"(raw[0].x));
                 if (stampN < 6u) stamps[stampN++] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // computed
 #endif
-            } else
+            } else {
+                // The plain code, for the blocks without a certificate or a staged footprint (near the camera, behind it,
+                // on the image's edge): a compact loop that takes its voxels from memory again and puts them back itself.
+                // Unrolled and on the registers of the loads above it costs the whole kernel 30 registers and its
+                // fifth wave per SIMD (measured: 99 against 65); the voxels are in the cache.
+                wrote = true;
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) {
+                    const uint4 r = vp[j * kWave];
+                    Vox v[2] = { unpack_vox(make_uint2(r.x, r.y)), unpack_vox(make_uint2(r.z, r.w)) };
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                Vox v[2] = { unpack_vox(make_uint2(raw[j].x, raw[j].y)), unpack_vox(make_uint2(raw[j].z, raw[j].w)) };
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    uint32_t sx, sy;
-                    float pz;
-                    if (project_voxel(hp, cp, mki3(ex * VH_SDF_BLOCK_SIZE + lx + k, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0), sx, sy, pz)) {
-                        const uint32_t tx = sx - x0, ty = sy - y0; // unsigned: a pixel left of / above the box wraps to a huge number
+                    for (int k = 0; k < 2; k++) {
+                        uint32_t sx, sy;
+                        float pz;
+                        if (project_voxel(hp, cp, mki3(ex * VH_SDF_BLOCK_SIZE + lx + k, ey * VH_SDF_BLOCK_SIZE + ly, ez * VH_SDF_BLOCK_SIZE + 2 * j + lz0), sx, sy, pz)) {
+                            const uint32_t tx = sx - x0, ty = sy - y0; // unsigned: a pixel left of / above the box wraps to a huge number
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 2 // measurement build: projection only
-                        v[k].cw ^= (tx + ty + __float_as_uint(pz)) & 1u;
+                            v[k].cw ^= (tx + ty + __float_as_uint(pz)) & 1u;
 #elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 3 // measurement build: projection + the pixel, no blend
-                        const uint2 px = (tx < w && ty < h) ? tile[ty * kIntegrateTileStride + tx] : packed[sy * cp.m_imageWidth + sx];
-                        v[k].cw ^= (px.x + px.y + __float_as_uint(pz)) & 1u;
+                            const uint2 px = (tx < w && ty < h) ? tile[ty * kIntegrateTileStride + tx] : packed[sy * cp.m_imageWidth + sx];
+                            v[k].cw ^= (px.x + px.y + __float_as_uint(pz)) & 1u;
 #else
-                        const uint2 px = (tx < w && ty < h) ? tile[ty * kIntegrateTileStride + tx] : packed[sy * cp.m_imageWidth + sx];
-                        v[k] = apply_pixel(hp, px, pz, v[k]);
+                            const uint2 px = (tx < w && ty < h) ? tile[ty * kIntegrateTileStride + tx] : packed[sy * cp.m_imageWidth + sx];
+                            v[k] = apply_pixel(hp, px, pz, v[k]);
 #endif
+                        }
                     }
+                    asm volatile("" : "+v"(v[0].sdf), "+v"(v[0].cw), "+v"(v[1].sdf), "+v"(v[1].cw)); // see integrate_pair
+                    if (flags & VH_FUSED_STARVE) { v[0] = starve_voxel(v[0]); v[1] = starve_voxel(v[1]); }
+                    minSdf = fminf(minSdf, fminf(gc_key(v[0]), gc_key(v[1])));
+                    maxW = max(maxW, max(v[0].weight(), v[1].weight()));
+                    const uint2 a = pack_vox(v[0]), c = pack_vox(v[1]);
+                    vp[j * kWave] = make_uint4(a.x, a.y, c.x, c.y);
                 }
-                asm volatile("" : "+v"(v[0].sdf), "+v"(v[0].cw), "+v"(v[1].sdf), "+v"(v[1].cw)); // see integrate_pair
-                if (flags & VH_FUSED_STARVE) { v[0] = starve_voxel(v[0]); v[1] = starve_voxel(v[1]); }
-                minSdf = fminf(minSdf, fminf(gc_key(v[0]), gc_key(v[1])));
-                maxW = max(maxW, max(v[0].weight(), v[1].weight()));
-                const uint2 a = pack_vox(v[0]), c = pack_vox(v[1]);
-                raw[j] = make_uint4(a.x, a.y, c.x, c.y);
             }
         } else {
 #if !(defined(VH_KNOCKOUT) && VH_KNOCKOUT == 1)
@@ -815,8 +898,13 @@ __global__ __launch_bounds__(256) void k_integrate_fused(VhHashData hd, VhHashPa
             }
             freed = __builtin_amdgcn_readfirstlane(f) != 0;
         }
+        if (freed) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) vp[j * kWave] = freed ? make_uint4(0u, 0u, 0u, 0u) : raw[j];
+            for (int j = 0; j < 4; j++) vp[j * kWave] = make_uint4(0u, 0u, 0u, 0u);
+        } else if (!wrote) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) vp[j * kWave] = raw[j];
+        }
         if (!hasNext) break;
         b += nActive;
     }
@@ -1965,7 +2053,8 @@ struct CoSplat {
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
 __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job, CoSplat splat)
 {
-    __shared__ SplatShared sh;
+    __shared__ union RiderShared { SplatShared splat; CompactShared compact; } shared;
+    SplatShared& sh = shared.splat;
     uint32_t g = blockIdx.x;
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 31 // measurement builds: the riders of this launch, one at a time
     if (g == 0u && splat.groups > splat.nSplatGroups) return; // no schedule workgroup
@@ -1986,7 +2075,7 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
     }
     g -= splat.groups;
     if (g < job.groups) {
-        compactify_words(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x);
+        compactify_group(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
         return;
     }
     g -= job.groups;
