@@ -330,6 +330,11 @@ private:
     SDFBlockDesc* h_SDFBlockDescInput;  // pinned staging for the worker's H2D
     vh::SDFBlock* h_SDFBlockInput;      // pinned
     uint32_t* h_counter;                // pinned
+    uint32_t* h_mirror;                 // mapped pinned: {word 0, word 1, tag} published by the device (vh_publish_words)
+    uint32_t* d_mirror;                 // its device alias
+    uint32_t m_mirrorTag;
+    // values of up to two device words once the stream has reached this point, without a blocking driver call
+    void readBack(const unsigned int* d_word0, const unsigned int* d_word1, unsigned int* out0, unsigned int* out1);
     SDFBlockDesc* d_SDFBlockDescOutput;
     SDFBlockDesc* d_SDFBlockDescInput;
     vh::SDFBlock* d_SDFBlockOutput;

@@ -166,6 +166,12 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
                            const VhRayCastParams* nextView, uint32_t* d_tileHeads, VhTileBlock* d_tileBlocks, uint32_t tileCapacity,
                            uint32_t* d_schedule, uint32_t phase, uint32_t* d_longestList, vhStream_t stream);
 
+/* Read-back without a blocking call: one thread writes {*d_src0, *d_src1 (0 where NULL), tag} -- the tag last, with
+ * system scope -- to d_mapped, the device alias of three words of mapped pinned host memory (vh_malloc_host memory is
+ * mapped).  The host polls word 2 for the tag.  Replaces the reference's blocking cudaMemcpy of the streaming counters
+ * (DSC/CUDASceneRepChunkGrid.cu:88, :140). */
+int vh_publish_words(const uint32_t* d_src0, const uint32_t* d_src1, uint32_t* d_mapped, uint32_t tag, vhStream_t stream);
+
 /* ---- streaming launchers: DSC/CUDASceneRepChunkGrid.h:142-146 --------------- */
 /* integrateFromGlobalHashPass1CUDA(params, hashData, threadsPerPart, start, radius, camPos,
  *                                  d_outputCounter, d_output)   DSC/CUDASceneRepChunkGrid.cu:76 */

@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -77,6 +79,7 @@ CUDASceneRepChunkGrid::CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSD
     m_maxNumberOfSDFBlocksIntegrateFromGlobalHash = 100000; // DSC/CUDASceneRepChunkGrid.h:162
     h_SDFBlockDescOutput = nullptr; h_SDFBlockOutput = nullptr;
     h_SDFBlockDescInput = nullptr; h_SDFBlockInput = nullptr; h_counter = nullptr;
+    h_mirror = nullptr; d_mirror = nullptr; m_mirrorTag = 0;
     d_SDFBlockDescOutput = nullptr; d_SDFBlockDescInput = nullptr;
     d_SDFBlockOutput = nullptr; d_SDFBlockInput = nullptr;
     d_SDFBlockCounter = nullptr; d_insertFailed = nullptr; d_bitMask = nullptr; m_copyStream = nullptr;
@@ -109,6 +112,9 @@ void CUDASceneRepChunkGrid::create(const vh::vec3f& voxelExtends, const vh::vec3
     checkHip(hipHostMalloc((void**)&h_SDFBlockDescInput, sizeof(SDFBlockDesc) * n, hipHostMallocDefault), "hipHostMalloc");
     checkHip(hipHostMalloc((void**)&h_SDFBlockInput, sizeof(vh::SDFBlock) * n, hipHostMallocDefault), "hipHostMalloc");
     checkHip(hipHostMalloc((void**)&h_counter, sizeof(uint32_t) * 2, hipHostMallocDefault), "hipHostMalloc");
+    checkHip(hipHostMalloc((void**)&h_mirror, sizeof(uint32_t) * 4, hipHostMallocMapped), "hipHostMalloc");
+    h_mirror[0] = h_mirror[1] = h_mirror[2] = h_mirror[3] = 0u;
+    checkHip(hipHostGetDevicePointer((void**)&d_mirror, h_mirror, 0), "hipHostGetDevicePointer");
     checkHip(hipMalloc((void**)&d_SDFBlockDescOutput, sizeof(SDFBlockDesc) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockDescInput, sizeof(SDFBlockDesc) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockOutput, sizeof(vh::SDFBlock) * n), "hipMalloc");
@@ -131,7 +137,7 @@ void CUDASceneRepChunkGrid::destroy()
     if (m_sceneRepHashSDF) (void)hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream());
     if (m_copyStream) { (void)hipStreamSynchronize((hipStream_t)m_copyStream); (void)hipStreamDestroy((hipStream_t)m_copyStream); }
     (void)hipHostFree(h_SDFBlockDescOutput); (void)hipHostFree(h_SDFBlockOutput);
-    (void)hipHostFree(h_SDFBlockDescInput); (void)hipHostFree(h_SDFBlockInput); (void)hipHostFree(h_counter);
+    (void)hipHostFree(h_SDFBlockDescInput); (void)hipHostFree(h_SDFBlockInput); (void)hipHostFree(h_counter); (void)hipHostFree(h_mirror);
     (void)hipFree(d_SDFBlockDescOutput); (void)hipFree(d_SDFBlockDescInput);
     (void)hipFree(d_SDFBlockOutput); (void)hipFree(d_SDFBlockInput);
     (void)hipFree(d_SDFBlockCounter); (void)hipFree(d_insertFailed); (void)hipFree(d_bitMask);
@@ -372,6 +378,29 @@ void CUDASceneRepChunkGrid::streamOutToCPU(const vh::vec3f& posCamera, float rad
     nStreamedBlocks = s_nStreamdOutBlocks;
 }
 
+// The reference reads its counters back with a blocking cudaMemcpy (DSC/CUDASceneRepChunkGrid.cu:88, :140).  Here a
+// one-thread kernel publishes them to mapped host memory behind the work already in the stream and the host polls the
+// tag: no synchronisation call, no copy.  (After two seconds without the tag it synchronises and copies after all.)
+void CUDASceneRepChunkGrid::readBack(const unsigned int* d_word0, const unsigned int* d_word1, unsigned int* out0, unsigned int* out1)
+{
+    vhStream_t stream = m_sceneRepHashSDF->getStream();
+    const uint32_t tag = ++m_mirrorTag ? m_mirrorTag : ++m_mirrorTag; // never 0
+    check(vh_publish_words(d_word0, d_word1, d_mirror, tag, stream), "vh_publish_words");
+    volatile uint32_t* m = h_mirror;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned int spins = 0;
+    while (m[2] != tag) {
+        if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            checkHip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+            if (m[2] != tag) throw vh::Error(-(int)hipErrorUnknown, "read-back: the device did not publish its counters");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (out0) *out0 = m[0];
+    if (out1) *out1 = m[1];
+}
+
 // DSC/CUDASceneRepChunkGrid.cpp:55-105
 void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded)
 {
@@ -401,7 +430,7 @@ void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, f
     check(vh_stream_out_pass1(&hd, &hp, threadsPerPart, start, radius, cam, d_SDFBlockCounter, d_SDFBlockDescOutput,
                               m_maxNumberOfSDFBlocksIntegrateFromGlobalHash, token, stream), "integrateFromGlobalHashPass1CUDA");
     unsigned int nSDFBlockDescs = 0;
-    check(vh_memcpy_d2h(&nSDFBlockDescs, d_SDFBlockCounter, sizeof(unsigned int), stream), "getSDFBlockCounter");
+    readBack(d_SDFBlockCounter, nullptr, &nSDFBlockDescs, nullptr);
     if (nSDFBlockDescs >= m_maxNumberOfSDFBlocksIntegrateFromGlobalHash) {
         if (multiThreaded) hEventOutProduce.set();
         throw vh::Error(VH_ERR_STAGING_OVERFLOW,
@@ -537,7 +566,7 @@ void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
         HashData& hd = m_sceneRepHashSDF->getHashData();
         vhStream_t stream = m_sceneRepHashSDF->getStream();
         unsigned int heapCountPrev = 0; // index of the top free block
-        check(vh_memcpy_d2h(&heapCountPrev, hd.d_heapCounter, sizeof(unsigned int), stream), "heapCounter");
+        readBack(hd.d_heapCounter, nullptr, &heapCountPrev, nullptr);
         if (s_nStreamdInBlocks > heapCountPrev + 1u) {
             if (multiThreaded) hEventInProduce.set();
             throw vh::Error(VH_ERR_HEAP_EXHAUSTED, "stream-in: not enough free SDF blocks");
@@ -551,9 +580,9 @@ void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
         // update heap counter (pinned source: stays valid until the copy ran)
         h_counter[0] = heapCountPrev - s_nStreamdInBlocks;
         checkHip(hipMemcpyAsync(hd.d_heapCounter, &h_counter[0], sizeof(unsigned int), hipMemcpyHostToDevice, hs), "heapCounter");
-        checkHip(hipMemcpyAsync(&h_counter[1], d_insertFailed, sizeof(unsigned int), hipMemcpyDeviceToHost, hs), "failed inserts");
-        checkHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
-        if (h_counter[1] != 0) takeBackFailedInserts(h_counter[1], heapCountPrev);
+        unsigned int nFailed = 0;
+        readBack(d_insertFailed, nullptr, &nFailed, nullptr); // (also: the copy above has read h_counter[0] by then)
+        if (nFailed != 0) takeBackFailedInserts(nFailed, heapCountPrev);
     }
     if (multiThreaded) hEventInProduce.set();
 }

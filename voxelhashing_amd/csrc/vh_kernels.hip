@@ -3679,6 +3679,24 @@ int vh_debug_hash_ops(const VhHashData* hd, const VhHashParams* hp, const int32_
     return vh_last_launch_error();
 }
 
+// {*src0, *src1, tag} into mapped host memory, the tag last and with system scope: a host that polls the tag reads
+// the two words without a stream synchronisation or a copy (each costs a blocking driver call; the streaming passes of
+// a frame need two such read-backs)
+__global__ void k_publish_words(const uint32_t* src0, const uint32_t* src1, uint32_t* mapped, uint32_t tag)
+{
+    mapped[0] = src0 ? *src0 : 0u;
+    mapped[1] = src1 ? *src1 : 0u;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(&mapped[2], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int vh_publish_words(const uint32_t* d_src0, const uint32_t* d_src1, uint32_t* d_mapped, uint32_t tag, vhStream_t stream)
+{
+    if (!d_mapped) return VH_ERR_BAD_ARGUMENT;
+    k_publish_words<<<1, 1, 0, (hipStream_t)stream>>>(d_src0, d_src1, d_mapped, tag);
+    return vh_last_launch_error();
+}
+
 int vh_debug_check_refined_division(uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream)
 {
     if (!d_mismatches) return VH_ERR_BAD_ARGUMENT;
