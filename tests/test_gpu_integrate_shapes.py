@@ -140,3 +140,84 @@ def test_certified_blocks_with_crafted_voxels(E, oracle_lib):
     canonical.assert_same_scene(gs, os_, "after the fused pass")
     # the crafted values were really blended: most crafted voxels changed
     assert gs["num_occupied"] > 100
+
+
+def test_compactify_queue_overflow_and_boxes(E, oracle_lib):
+    """4096 buckets are ONE compactify workgroup; a dense scene leaves more in-frustum blocks than its LDS queue takes
+    (768): the rest go straight to the list.  Every entry of the list carries its block's screen box, flags and the
+    frame's tag; the list as a set and the pass over it equal the oracle's."""
+    O = oracle_lib
+    hp, cp, rp = small_config(160, 120, params="P2", num_buckets=1 << 12, num_sdf_blocks=1 << 13)
+    opt = T.make_scene_options(offline=True, gc=True, starve=2)
+    spheres, inside, radius = synth.scene("S2")
+    scene, ref = E.CUDASceneRepHashSDF(hp, opt), O.OracleScene(hp, cp, rp, opt)
+    frame = E.DepthFrame(cp)
+    for k in range(3):
+        pose = synth.orbit_pose(k, 300, radius)
+        E.synth_frame(spheres, inside, pose, cp, out=frame)
+        d, c = O.synth_frame(spheres, inside, pose, cp)
+        scene.integrate(pose, frame, cp, None)
+        ref.integrate(pose, d, c)
+        canonical.assert_same_scene(scene.state(), ref.state(), f"frame {k}")
+    raw = scene.download(with_voxels=False)
+    n = raw["compact_count"]
+    assert n > 768 + 64, n
+    comp = raw["compactified"]
+    pad = comp["_pad"].view(np.uint32)
+    assert len(np.unique(pad[:, 2])) == 1 and pad[0, 2] != 0, "one tag, not zero, on every entry"
+    x0, y0 = pad[:, 0] & 0xFFFF, pad[:, 0] >> 16
+    w, h, flags = pad[:, 1] & 0xFF, (pad[:, 1] >> 8) & 0xFF, pad[:, 1] >> 16
+    staged = (flags & 1) != 0
+    assert staged.sum() > n // 2 and ((flags & 2) != 0).sum() > n // 2
+    assert ((x0[staged] & 1) == 0).all() and (x0[staged] + w[staged] <= cp.m_imageWidth).all() and (y0[staged] + h[staged] <= cp.m_imageHeight).all()
+    assert (w[staged] >= 1).all() and (w[staged] <= 32).all() and (h[staged] >= 1).all() and (h[staged] <= 29).all()
+    assert (w[~staged] == 0).all() and (h[~staged] == 0).all()
+
+
+def test_list_made_for_another_transform_takes_the_plain_code(E, oracle_lib):
+    """launcher level: compactify under one pose, the fused pass under another (nobody does that; the list's boxes and
+    certificates are then for the wrong transform and the tag says so): every block goes through the plain code, and the
+    result is the oracle's for the same two calls"""
+    from voxelhashing_amd.lib import DeviceBuffer
+    O = oracle_lib
+    hp, cp, rp = small_config(160, 120, params="P2", num_buckets=1 << 12, num_sdf_blocks=4096)  # 1024 workgroups
+    spheres, inside, radius = synth.scene("S2")
+    pose_a, pose_b = synth.orbit_pose(0, 300, radius), synth.orbit_pose(2, 300, radius)
+    g = E.LauncherScene(hp)
+    o = O.OracleScene(hp, cp, rp, T.make_scene_options(offline=True, gc=True))
+    frame = E.DepthFrame(cp)
+    E.synth_frame(spheres, inside, pose_a, cp, out=frame)
+    depth, color = O.synth_frame(spheres, inside, pose_a, cp)
+    g.set_transform(pose_a, O.mat4_inverse(pose_a))
+    o.set_transform(pose_a)
+    packed = DeviceBuffer(8 * cp.m_imageWidth * cp.m_imageHeight)
+    job = g.frame_job(frame, cp, packed_ptr=packed.ptr)
+    prev = -1
+    while True:  # alloc until the heap stops changing; every pass packs the frame as well
+        g.reset_mutex()
+        g.alloc_job(job)
+        cur = g.download(with_voxels=False)["heap_counter"]
+        if cur == prev:
+            break
+        prev = cur
+    prev = -1
+    while True:
+        o.reset_mutex()
+        o.alloc(depth, color)
+        cur = o.heap_free_count()
+        if cur == prev:
+            break
+        prev = cur
+    canonical.assert_same_scene(g.state(), o.state(), "after alloc")
+    n = g.compactify(cp)
+    assert n == o.compactify() and 1024 < n < 4096, n  # the wave-per-block shape
+    g.set_transform(pose_b, O.mat4_inverse(pose_b))
+    o.set_transform(pose_b)
+    g.reset_mutex()
+    g.integrate_fused(frame, cp, 3, T.LOCK_ENTRY, packed.ptr)
+    o.integrate_depth_map(depth, color)
+    o.starve()
+    o.gc_identify()
+    o.reset_mutex()
+    o.gc_free()
+    canonical.assert_same_scene(g.state(), o.state(), "after the fused pass under the other pose")
