@@ -604,8 +604,15 @@ VHD void integrate_block_certified(const VhHashParams& hp, const VhDepthCameraPa
                                    uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, int ex, int ey, int ez, uint32_t lane, uint32_t flags,
                                    uint4 (&raw)[4], float& minSdf, uint32_t& maxW)
 {
-    const float vs = hp.m_virtualVoxelSize;
-    const float* m = hp.m_rigidTransformInverse;
+    // (The transform as values of this function's own: packed instructions want their uniform operands in vector registers,
+    // and copies shared with the kernel's other code paths live from the top of the kernel to its end -- the compiler
+    // parks them in scratch memory, a store per lane of every wave of the launch.)
+    float vs = hp.m_virtualVoxelSize;
+    float m[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) m[i] = hp.m_rigidTransformInverse[i];
+    asm volatile("" : "+s"(vs), "+s"(m[0]), "+s"(m[1]), "+s"(m[2]), "+s"(m[3]), "+s"(m[4]), "+s"(m[5]), "+s"(m[6]), "+s"(m[7]), "+s"(m[8]), "+s"(m[9]),
+                      "+s"(m[10]), "+s"(m[11]));
     const int lx = (int)((2u * lane) & 7u), ly = (int)((lane >> 2) & 7u), lz0 = (int)(lane >> 5);
     // vvp_to_world, mat_mul_p: ((m0 x + m1 y) + m2 z) + m3 per row; the first sum does not depend on z
     const f32x2 xw = (f32x2){ (float)(ex * VH_SDF_BLOCK_SIZE + lx), (float)(ex * VH_SDF_BLOCK_SIZE + lx + 1) } * vs;
@@ -682,12 +689,49 @@ VHD void integrate_block_certified(const VhHashParams& hp, const VhDepthCameraPa
 }
 
 constexpr uint32_t kIntegrateWavesMost = 5120; // waves that take blocks when there are many: five per SIMD
-template <bool PACKED>
-__global__ __launch_bounds__(256) // WAVES_ATTR
-void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, VhDepthCameraParams cp,
-                                                         uint32_t flags, int32_t lockToken, uint32_t* countMirror, uint32_t mirrorTag,
-                                                         const uint2* packed)
+// The kernel's one argument.  The pass that frees a block (a handful of blocks per frame, one lane each) wants a dozen
+// table pointers and sizes that nothing else in the kernel needs; as ordinary kernel arguments they are loaded at the top
+// of the kernel and kept in scalar registers throughout -- or, as measured, parked in scratch memory by every wave of
+// the launch (4.5 MB of stores per launch at cfg2).  cold_args() hands that pass the argument block as memory the
+// compiler knows nothing about, so it loads what it needs where it needs it.
+struct FusedArgs {
+    VhHashData hd;
+    VhHashParams hp;
+    VhDepthCameraData cam;
+    VhDepthCameraParams cp;
+    uint32_t flags;
+    int32_t lockToken;
+    uint32_t* countMirror;
+    uint32_t mirrorTag;
+    const uint2* packed;
+};
+VHD const FusedArgs* cold_args()
 {
+    typedef const char __attribute__((address_space(4))) * KernargPtr;
+    KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const FusedArgs*)p;
+}
+VHD bool free_block_cold(int ex, int ey, int ez)
+{
+    const FusedArgs* a = cold_args();
+    const VhHashData hd = a->hd;
+    const VhHashParams hp = a->hp;
+    return delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), a->lockToken);
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256)
+void k_integrate_fused(FusedArgs args)
+{
+    const VhHashData& hd = args.hd;
+    const VhHashParams& hp = args.hp;
+    const VhDepthCameraData& cam = args.cam;
+    const VhDepthCameraParams& cp = args.cp;
+    const uint32_t flags = args.flags;
+    uint32_t* const countMirror = args.countMirror;
+    const uint32_t mirrorTag = args.mirrorTag;
+    const uint2* const packed = args.packed;
     __shared__ float sMin[4];
     __shared__ uint32_t sMax[4];
     __shared__ int sFreed;
@@ -740,7 +784,7 @@ void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, Vh
             const bool decide = (minSdf >= thr) || (maxW == 0u); // the same in every thread of the workgroup
             if (t == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
             if (decide) {
-                if (t == 0) sFreed = delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), lockToken) ? 1 : 0;
+                if (t == 0) sFreed = free_block_cold(ex, ey, ez) ? 1 : 0;
                 __syncthreads();
                 if (sFreed != 0) raw = make_uint4(0u, 0u, 0u, 0u);
             }
@@ -894,7 +938,7 @@ void k_integrate_fused(VhHashData hd, VhHashParams hp, VhDepthCameraData cam, Vh
             int f = 0;
             if (lane == 0) {
                 hd.d_hashDecision[b] = decide ? 1 : 0;
-                f = (decide && delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), lockToken)) ? 1 : 0;
+                f = (decide && free_block_cold(ex, ey, ez)) ? 1 : 0;
             }
             freed = __builtin_amdgcn_readfirstlane(f) != 0;
         }
@@ -3251,8 +3295,12 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
     const uint32_t want = cdiv(hp->m_numSDFBlocks, 4), most = device_num_cus() * 8u;
     const uint32_t grid = want < most ? want : most;
     const uint2* packed = reinterpret_cast<const uint2*>(d_packedFrame);
-    if (packed) k_integrate_fused<true><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken, d_countMirror, mirrorTag, packed);
-    else k_integrate_fused<false><<<grid, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cam, *cp, flags, lockToken, d_countMirror, mirrorTag, nullptr);
+    FusedArgs args;
+    args.hd = *hd; args.hp = *hp; args.cam = *cam; args.cp = *cp;
+    args.flags = flags; args.lockToken = lockToken; args.countMirror = d_countMirror; args.mirrorTag = mirrorTag;
+    args.packed = reinterpret_cast<const uint2*>(packed);
+    if (packed) k_integrate_fused<true><<<grid, 256, 0, (hipStream_t)stream>>>(args);
+    else k_integrate_fused<false><<<grid, 256, 0, (hipStream_t)stream>>>(args);
     return vh_last_launch_error();
 }
 
