@@ -615,8 +615,7 @@ def main(argv=None):
             hl.set_event_stride(1 << 30)
             # untimed pass over every frame first: the first transfer out of a freshly pinned page is several times
             # slower than the following ones (the main workload's pre-roll does the same for its frames)
-            hl.run(0, hw + hs)
-            hl.restart()
+            preroll(hl, max(args.preroll_seconds, 0.3))
             hl.run(0, hw)
             hl.recon.synchronize()
             torch.cuda.synchronize()
