@@ -497,6 +497,34 @@ VHD bool delete_hash_entry_element(const VhHashData& hd, const VhHashParams& hp,
     return false;
 }
 
+// deleteHashEntryElement for a whole wave that frees ONE block (every lane calls it with the same block): ten lanes read
+// the bucket's ten slots together instead of one lane reading them one after the other (up to ten dependent trips to
+// memory at the end of a wave's life), and the lane that finds the block frees it with its two counter atomics in flight
+// together.  An element of a collision list (a head with an offset, or a block that is not in its bucket) goes through
+// the one-lane code.  Returns the same value in every lane.
+VHD bool delete_hash_entry_element_wave(const VhHashData& hd, const VhHashParams& hp, I3 blk, int32_t lockToken, uint32_t lane)
+{
+    const uint32_t h = hash_pos(hp.m_hashNumBuckets, blk);
+    const uint32_t i = h * VH_HASH_BUCKET_SIZE + lane;
+    int4 q = make_int4(0, 0, 0, VH_FREE_ENTRY);
+    uint32_t off = 0u;
+    if (lane < VH_HASH_BUCKET_SIZE) { q = load_quad(&hd.d_hash[i]); off = hd.d_hash[i].offset; }
+    const bool match = lane < VH_HASH_BUCKET_SIZE && quad_matches(q, blk);
+    const unsigned long long m = __ballot(match);
+    bool ok = false;
+    if (m == 0ull || __ballot(match && off != 0u) != 0ull) {
+        if (lane == 0u) ok = delete_hash_entry_element(hd, hp, blk, lockToken);
+    } else if (match) { // (a block sits in at most one slot)
+        const uint32_t addr = atomicAdd(&hd.d_heapCounter[0], 1u);          // append_heap
+        const uint32_t old = atomicSub(&hd.d_bucketCount[h], 1u);           // bucket_dec
+        hd.d_heap[addr + 1] = (uint32_t)q.w / VH_SDF_BLOCK_VOXELS;
+        delete_hash_entry(&hd.d_hash[i]);
+        if (old == 1u) atomicAnd(&hd.d_bucketBits[h >> 5], ~(1u << (h & 31)));
+        ok = true;
+    }
+    return __ballot(ok) != 0ull;
+}
+
 // ---------------------------------------------------------------------------
 // voxels.  A voxel is moved as one 64-bit word (DSC/VoxelUtilHashSDF.h:82-86):
 // low dword = sdf bits, high dword = r | g<<8 | b<<16 | weight<<24.

@@ -712,12 +712,12 @@ VHD const FusedArgs* cold_args()
     asm volatile("" : "+s"(p));
     return (const FusedArgs*)p;
 }
-VHD bool free_block_cold(int ex, int ey, int ez)
+VHD bool free_block_cold(int ex, int ey, int ez, uint32_t lane) // every lane of the wave calls it
 {
     const FusedArgs* a = cold_args();
     const VhHashData hd = a->hd;
     const VhHashParams hp = a->hp;
-    return delete_hash_entry_element(hd, hp, mki3(ex, ey, ez), a->lockToken);
+    return delete_hash_entry_element_wave(hd, hp, mki3(ex, ey, ez), a->lockToken, lane);
 }
 
 template <bool PACKED>
@@ -784,7 +784,10 @@ void k_integrate_fused(FusedArgs args)
             const bool decide = (minSdf >= thr) || (maxW == 0u); // the same in every thread of the workgroup
             if (t == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
             if (decide) {
-                if (t == 0) sFreed = free_block_cold(ex, ey, ez) ? 1 : 0;
+                if (wave == 0u) {
+                    const bool f = free_block_cold(ex, ey, ez, lane);
+                    if (lane == 0u) sFreed = f ? 1 : 0;
+                }
                 __syncthreads();
                 if (sFreed != 0) raw = make_uint4(0u, 0u, 0u, 0u);
             }
@@ -804,7 +807,12 @@ void k_integrate_fused(FusedArgs args)
     const uint64_t stampC0 = __builtin_amdgcn_s_memtime(), stampR0 = __builtin_amdgcn_s_memrealtime();
     uint32_t stamps[6] = { 0u, 0u, 0u, 0u, 0u, 0u }, stampN = 0u; // per block: staged, voxels arrived, computed (two blocks)
 #endif
-    uint32_t b = wFirst;
+    uint32_t b = wFirst, round = 0u;
+    // this wave's place in the later rounds: the SIMD it sits on (unit g mod 256, wave of the workgroup) bit-reversed, then
+    // the workgroup's turn on that unit -- a permutation of 0 .. 5119 whose every prefix is spread evenly over the SIMDs
+    // (used as is when all 5 120 waves are active; with fewer waves, which happens below 5 120 blocks, there is one round)
+    const uint32_t simdOfMachine = ((blockIdx.x & 255u) << 2) | wave;
+    const uint32_t scattered = nActive == kIntegrateWavesMost ? (__brev(simdOfMachine) >> 22) + (blockIdx.x >> 8) * 1024u : wFirst;
     int4 q = qw;
     uint4 qbox = boxw;
     uint2* tile = sTile[wave];
@@ -821,11 +829,18 @@ void k_integrate_fused(FusedArgs args)
         uint4 raw[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) raw[j] = vp[j * kWave];
-        if (PACKED) qbox = *(reinterpret_cast<const uint4*>(&hd.d_hashCompactified[b]) + 1);
         const uint32_t boxA = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbox.y), boxB = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbox.z);
         const uint32_t boxTag = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbox.w);
-        const bool hasNext = b + nActive < count;
-        if (hasNext) q = load_quad(&hd.d_hashCompactified[b + nActive]); // the next block's entry behind this block's voxels
+        // The wave's next block.  Rounds of nActive blocks; within a round the blocks go to the waves in an order that
+        // scatters a partial last round over the compute units (workgroup g sits on unit g mod 256: with the plain order
+        // w + round * nActive the first units get all of the last round's blocks -- 36 blocks against 32 at 8 600).
+        round += 1u;
+        const uint32_t bNext = round * nActive + scattered;
+        const bool hasNext = scattered < nActive && bNext < count;
+        if (hasNext) { // its entry (both halves) behind this block's voxels
+            q = load_quad(&hd.d_hashCompactified[bNext]);
+            if (PACKED) qbox = *(reinterpret_cast<const uint4*>(&hd.d_hashCompactified[bNext]) + 1);
+        }
         // (Requesting the next block's voxels here as well was measured: slower.  The waves do not wait for the stream --
         // the kernel is bound by instruction issue, ~1000 vector instructions per block at 4 cycles each.)
 
@@ -935,12 +950,9 @@ void k_integrate_fused(FusedArgs args)
                 maxW = max(maxW, (uint32_t)__shfl_xor((int)maxW, o));
             }
             const bool decide = (minSdf >= thr) || (maxW == 0u);
-            int f = 0;
-            if (lane == 0) {
-                hd.d_hashDecision[b] = decide ? 1 : 0;
-                f = (decide && free_block_cold(ex, ey, ez)) ? 1 : 0;
-            }
-            freed = __builtin_amdgcn_readfirstlane(f) != 0;
+            if (lane == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
+            // (the same decision in every lane: the reduction left every lane with the block's minimum and maximum)
+            if (__builtin_amdgcn_readfirstlane(decide ? 1 : 0) != 0) freed = free_block_cold(ex, ey, ez, lane);
         }
         if (freed) {
 #pragma unroll
@@ -950,7 +962,7 @@ void k_integrate_fused(FusedArgs args)
             for (int j = 0; j < 4; j++) vp[j * kWave] = raw[j];
         }
         if (!hasNext) break;
-        b += nActive;
+        b = bNext;
     }
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9
     if (wFirst == 0u && lane == 0u) {
