@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -258,6 +259,19 @@ public:
     void streamInToGPU(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int& nStreamedBlocks);
     void streamInToGPUPass0CPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded = true);
     void streamInToGPUPass1GPU(bool multiThreaded = true);
+
+    // ---- the streaming step of a frame in which nothing streams, kept out of the frame's launches (no reference twin;
+    // used by Reconstruction when it knows the next frame's pose).  probeStreamOut() enqueues the scan the NEXT stream-out
+    // pass will make, counting only; probeResult() waits for its answer.  With the answer 0, streamOutNothing() is that
+    // pass without its launches (same protocol with the worker thread, same part counter), and streamInWait() /
+    // streamInFinish() are the two halves of streamInToGPUPass1GPU(true): the worker's answer first, the launches -- if
+    // any block comes in -- wherever the caller's launch order wants them.
+    void probeStreamOut(const vh::vec3f& posCamera, float radius, bool useParts);
+    unsigned int probeResult();
+    void streamOutNothing(const vh::vec3f& posCamera, float radius, bool useParts);
+    unsigned int streamInWait();
+    void streamInFinish();
+    bool bitMaskDirty() const { return m_bitMaskDirty; }
     unsigned int integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts);
     // blocks that stream-in passes could not insert and that went back to the host grid (not in the reference)
     unsigned int getNumFailedInserts() const { return m_numFailedInserts; }
@@ -309,7 +323,7 @@ private:
     struct AutoResetEvent { // Win32 auto-reset event (CreateEvent(NULL, FALSE, initial, NULL))
         std::mutex mtx;
         std::condition_variable cv;
-        bool signaled = false;
+        std::atomic<bool> signaled{ false };
         void set();
         void wait();
         void reset(bool state);
@@ -321,6 +335,7 @@ private:
     void setBit(unsigned int index);
     void resetBit(unsigned int index);
     void takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev);
+    void streamInLaunches();
     unsigned int m_numFailedInserts;
 
     unsigned int m_maxNumberOfSDFBlocksIntegrateFromGlobalHash;
@@ -333,6 +348,11 @@ private:
     uint32_t* h_mirror;                 // mapped pinned: {word 0, word 1, tag} published by the device (vh_publish_words)
     uint32_t* d_mirror;                 // its device alias
     uint32_t m_mirrorTag;
+    uint32_t* h_probe;                  // mapped pinned: {count, 0, tag} of the stream-out probe
+    uint32_t* d_probe;                  // its device alias
+    uint32_t m_probeTag;
+    unsigned int* d_probeCounter;
+    std::unique_lock<std::mutex> m_streamInLock; // held between streamInWait() and streamInFinish()
     // values of up to two device words once the stream has reached this point, without a blocking driver call
     void readBack(const unsigned int* d_word0, const unsigned int* d_word1, unsigned int* out0, unsigned int* out1);
     SDFBlockDesc* d_SDFBlockDescOutput;
@@ -395,7 +415,9 @@ public:
     const ReconstructionStats& getStats();
 
 private:
-    void frame(const SequenceFrame& f);
+    void frame(const SequenceFrame& f, const SequenceFrame* next);
+    bool m_probePending;        // a stream-out probe for the frame with pose m_probePose is in the stream
+    float m_probePose[16];
     DepthCameraData upload(const SequenceFrame& f);
 
     CUDASceneRepHashSDF* m_sceneRep;

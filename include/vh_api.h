@@ -178,6 +178,12 @@ int vh_publish_words(const uint32_t* d_src0, const uint32_t* d_src1, uint32_t* d
 int vh_stream_out_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start,
                         float radius, const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_output,
                         uint32_t outputCapacity, int32_t lockToken, vhStream_t stream);
+/* The scan of vh_stream_out_pass1 without its deletes: the number of blocks the pass would move out, published as
+ * {count, 0, tag} to d_mapped (device alias of mapped host memory, see vh_publish_words); *d_counter must be zero and is
+ * zero again afterwards.  No reference twin: it lets a frame loop that knows its poses ahead skip the streaming step of a
+ * frame in which nothing would stream (CUDASceneRepChunkGrid::probeStreamOut). */
+int vh_stream_out_probe(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start, float radius,
+                        const float camPos[3], uint32_t* d_counter, uint32_t* d_mapped, uint32_t tag, vhStream_t stream);
 /* integrateFromGlobalHashPass2CUDA(params, hashData, threadsPerPart, descs, d_output, n)  :115 */
 int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSDFBlockDesc* d_descs,
                         VhVoxel* d_output, uint32_t nSDFBlocks, vhStream_t stream);

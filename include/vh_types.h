@@ -264,6 +264,7 @@ typedef struct VhReconstructionStats {
     double uploadMs;             /* device time of the timed frame uploads (copy stream, HIP events) */
     uint64_t uploadsTimed;
     uint64_t uploadBytes;        /* bytes per frame upload */
+    uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to be a no-op and ran with three launches */
 } VhReconstructionStats;
 
 /* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt

@@ -177,3 +177,59 @@ def test_per_frame_streaming_at_cfg3_size_keeps_every_invariant(vh):
     assert hits > 20000
     recon.close()
     grid.close()
+
+
+@pytest.mark.parametrize("radius", [RADIUS, 5.0])
+def test_streaming_step_decided_ahead_changes_nothing(vh, radius):
+    """The native loop asks the device a frame early whether the next stream-out pass will find anything
+    (vh_stream_out_probe) and, when neither that nor the worker has anything to move, runs the frame with its three
+    launches as if streaming were off.  The same 60 frames with the question asked (s_allocAhead on) and without
+    (off: every frame takes the reference's order of calls): the table, the voxels, the host chunk grid, the ray-cast
+    maps after every batch and the streaming counters are the same, and both kinds of frame occurred."""
+    from voxelhashing_amd import engine as E
+    hp, cp, rp = small_config(160, 120, num_buckets=1 << 15, num_sdf_blocks=1 << 13, streaming_extents=EXT, streaming_dims=DIMS, streaming_min=MINP)
+    n = 60
+    off = np.array([7.3, 5.1, 3.7], np.float32)  # away from the origin: online alloc is deterministic there (test_gpu_frame_loop.py)
+    spheres = synth.S1_SPHERES.copy()
+    spheres[:, :3] += off
+    poses = []
+    for k in range(n):
+        q = np.array(synth.orbit_pose(k, 120), dtype=np.float32).copy()
+        q[3] += off[0]; q[7] += off[1]; q[11] += off[2]
+        poses.append(q)
+
+    def run(ahead):
+        opt = T.make_scene_options(offline=False, gc=True, starve=15, streaming_out_parts=PARTS)
+        scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+        grid = E.CUDASceneRepChunkGrid(scene, EXT, DIMS, MINP, 64, True, PARTS)
+        frames = [E.synth_frame(spheres, 0, p, cp) for p in poses]
+        recon = E.Reconstruction(scene, ray, grid, cp, E.Reconstruction.defaultOptions(s_streamingEnabled=1, s_streamingPos=STREAM_POS[:3], s_streamingRadius=radius,
+                                                                                      s_allocAhead=1 if ahead else 0, s_maxFramesInFlight=4))
+        seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+        maps = []
+        for k0 in range(0, n, 20):
+            recon.run(seq, k0, 20)
+            recon.synchronize()
+            maps.append(ray.download())
+        stats = recon.getStats()
+        host = sorted_blocks(*grid.downloadHostBlocks())
+        grid.debugCheckForDuplicates()
+        grid.reset()
+        state = scene.state()
+        recon.close()
+        grid.close()
+        return state, host, maps, stats
+
+    sa, ha, ma, ta = run(True)
+    sb, hb, mb, tb = run(False)
+    canonical.assert_same_scene(sa, sb, "decided ahead vs the reference's order")
+    assert np.array_equal(ha[0], hb[0]) and ha[1].tobytes() == hb[1].tobytes(), "host chunk grids differ"
+    for i, (a, b) in enumerate(zip(ma, mb)):
+        for m in ("depth", "depth4", "colors", "normals"):
+            assert np.array_equal(a[m].view(np.uint32), b[m].view(np.uint32)), f"batch {i}: raycast map {m} differs"
+    assert (ta["blocksStreamedOut"], ta["blocksStreamedIn"]) == (tb["blocksStreamedOut"], tb["blocksStreamedIn"])
+    assert tb["streamingStepsSkipped"] == 0 and ta["frames"] == n
+    if radius == RADIUS:  # blocks leave in most frames, a few frames have nothing to move
+        assert ta["blocksStreamedOut"] > 20 and 1 <= ta["streamingStepsSkipped"] < n - 5, ta
+    else:  # the sphere holds the whole scene: every frame but the first of each run() call (nobody asked about that one)
+        assert ta["blocksStreamedOut"] == 0 and ta["streamingStepsSkipped"] == n - 3, ta

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--launches", type=int, default=200)
     ap.add_argument("--gc", action="store_true")
+    ap.add_argument("--in-loop", action="store_true", help="no repeated launches: the time stamps of the frame loop's last integrate launch (a -DVH_KNOCKOUT=9 build)")
     a = ap.parse_args()
     import torch
     from voxelhashing_amd import engine as E, lib, synth, vhtypes as T
@@ -44,7 +45,7 @@ def main():
     torch.cuda.synchronize()
     flags = 1 if a.gc else 0
     out = {}
-    for what, pk in (("unpacked", None), ("packed", packed)):
+    for what, pk in (() if a.in_loop else (("unpacked", None), ("packed", packed))):
         for _ in range(10):
             check(L.vh_integrate_fused(C.byref(hd), C.byref(hpp), C.byref(frame.data), C.byref(cp), flags, 12345, None, 0, pk, None), "integrate")
         torch.cuda.synchronize()

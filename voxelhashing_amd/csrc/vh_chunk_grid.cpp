@@ -53,9 +53,17 @@ void CUDASceneRepChunkGrid::AutoResetEvent::set()
 }
 void CUDASceneRepChunkGrid::AutoResetEvent::wait()
 {
+    // Frames come every 100-250 us and each hands over to the other thread four times: a condition variable's wake-up
+    // (tens of microseconds) would be most of the frame's slack.  So the waiter looks at the flag for a frame or two first
+    // and only then goes to sleep.
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned int spins = 0;
+    while (!signaled.load(std::memory_order_acquire)) {
+        if ((++spins & 0xffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+    }
     std::unique_lock<std::mutex> l(mtx);
-    cv.wait(l, [this] { return signaled; });
-    signaled = false;
+    cv.wait(l, [this] { return signaled.load(std::memory_order_acquire); });
+    signaled.store(false, std::memory_order_release);
 }
 void CUDASceneRepChunkGrid::AutoResetEvent::reset(bool state)
 {
@@ -80,6 +88,7 @@ CUDASceneRepChunkGrid::CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSD
     h_SDFBlockDescOutput = nullptr; h_SDFBlockOutput = nullptr;
     h_SDFBlockDescInput = nullptr; h_SDFBlockInput = nullptr; h_counter = nullptr;
     h_mirror = nullptr; d_mirror = nullptr; m_mirrorTag = 0;
+    h_probe = nullptr; d_probe = nullptr; m_probeTag = 0; d_probeCounter = nullptr;
     d_SDFBlockDescOutput = nullptr; d_SDFBlockDescInput = nullptr;
     d_SDFBlockOutput = nullptr; d_SDFBlockInput = nullptr;
     d_SDFBlockCounter = nullptr; d_insertFailed = nullptr; d_bitMask = nullptr; m_copyStream = nullptr;
@@ -115,6 +124,11 @@ void CUDASceneRepChunkGrid::create(const vh::vec3f& voxelExtends, const vh::vec3
     checkHip(hipHostMalloc((void**)&h_mirror, sizeof(uint32_t) * 4, hipHostMallocMapped), "hipHostMalloc");
     h_mirror[0] = h_mirror[1] = h_mirror[2] = h_mirror[3] = 0u;
     checkHip(hipHostGetDevicePointer((void**)&d_mirror, h_mirror, 0), "hipHostGetDevicePointer");
+    checkHip(hipHostMalloc((void**)&h_probe, sizeof(uint32_t) * 4, hipHostMallocMapped), "hipHostMalloc");
+    h_probe[0] = h_probe[1] = h_probe[2] = h_probe[3] = 0u;
+    checkHip(hipHostGetDevicePointer((void**)&d_probe, h_probe, 0), "hipHostGetDevicePointer");
+    checkHip(hipMalloc((void**)&d_probeCounter, sizeof(unsigned int)), "hipMalloc");
+    checkHip(hipMemset(d_probeCounter, 0, sizeof(unsigned int)), "hipMemset");
     checkHip(hipMalloc((void**)&d_SDFBlockDescOutput, sizeof(SDFBlockDesc) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockDescInput, sizeof(SDFBlockDesc) * n), "hipMalloc");
     checkHip(hipMalloc((void**)&d_SDFBlockOutput, sizeof(vh::SDFBlock) * n), "hipMalloc");
@@ -137,7 +151,7 @@ void CUDASceneRepChunkGrid::destroy()
     if (m_sceneRepHashSDF) (void)hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream());
     if (m_copyStream) { (void)hipStreamSynchronize((hipStream_t)m_copyStream); (void)hipStreamDestroy((hipStream_t)m_copyStream); }
     (void)hipHostFree(h_SDFBlockDescOutput); (void)hipHostFree(h_SDFBlockOutput);
-    (void)hipHostFree(h_SDFBlockDescInput); (void)hipHostFree(h_SDFBlockInput); (void)hipHostFree(h_counter); (void)hipHostFree(h_mirror);
+    (void)hipHostFree(h_SDFBlockDescInput); (void)hipHostFree(h_SDFBlockInput); (void)hipHostFree(h_counter); (void)hipHostFree(h_mirror); (void)hipHostFree(h_probe); (void)hipFree(d_probeCounter);
     (void)hipFree(d_SDFBlockDescOutput); (void)hipFree(d_SDFBlockDescInput);
     (void)hipFree(d_SDFBlockOutput); (void)hipFree(d_SDFBlockInput);
     (void)hipFree(d_SDFBlockCounter); (void)hipFree(d_insertFailed); (void)hipFree(d_bitMask);
@@ -450,6 +464,77 @@ void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, f
     if (multiThreaded) hEventOutConsume.set();
 }
 
+// ---- a frame in which nothing streams (see vh.hpp) ----------------------------------------------------------------
+
+void CUDASceneRepChunkGrid::probeStreamOut(const vh::vec3f& posCamera, float radius, bool useParts)
+{
+    const HashParams& hp = m_sceneRepHashSDF->getHashParams();
+    HashData& hd = m_sceneRepHashSDF->getHashData();
+    const unsigned int numEntries = hp.m_hashNumBuckets * hp.m_hashBucketSize;
+    unsigned int threadsPerPart = (numEntries + m_streamOutParts - 1) / m_streamOutParts;
+    if (!useParts) threadsPerPart = numEntries;
+    const unsigned int start = useParts ? m_currentPart * threadsPerPart : 0; // the part the NEXT pass 0 scans
+    const float cam[3] = { posCamera.x, posCamera.y, posCamera.z };
+    m_probeTag = ++m_probeTag ? m_probeTag : 1u;
+    check(vh_stream_out_probe(&hd, &hp, threadsPerPart, start, radius, cam, d_probeCounter, d_probe, m_probeTag, m_sceneRepHashSDF->getStream()),
+          "vh_stream_out_probe");
+}
+
+unsigned int CUDASceneRepChunkGrid::probeResult()
+{
+    volatile uint32_t* m = h_probe;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned int spins = 0;
+    while (m[2] != m_probeTag) {
+        if ((++spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            checkHip(hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream()), "hipStreamSynchronize");
+            if (m[2] != m_probeTag) throw vh::Error(-(int)hipErrorUnknown, "stream-out probe: the device did not publish its count");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return m[0];
+}
+
+// streamOutToCPUPass0GPU(multiThreaded = true) of a part the probe found nothing to move out of
+void CUDASceneRepChunkGrid::streamOutNothing(const vh::vec3f& posCamera, float radius, bool useParts)
+{
+    if (s_terminateThread) throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamOutNothing: the streaming thread is not running");
+    hEventOutProduce.wait();
+    {
+        std::lock_guard<std::mutex> lock(hMutexOut);
+        s_posCamera = posCamera;
+        s_radius = radius;
+        (void)m_sceneRepHashSDF->nextLockToken(); // (the pass draws one: keep the sequence of tokens the same)
+        if (useParts) m_currentPart = (m_currentPart + 1) % m_streamOutParts;
+        s_nStreamdOutBlocks = 0;
+    }
+    hEventOutConsume.set();
+}
+
+unsigned int CUDASceneRepChunkGrid::streamInWait()
+{
+    if (s_terminateThread || m_sceneRepHashSDF->getOptions().s_offlineProcessing)
+        throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamInWait: no worker thread prepares the pass (offline processing, or streaming thread stopped)");
+    hEventInConsume.wait();
+    m_streamInLock = std::unique_lock<std::mutex>(hMutexIn);
+    return s_nStreamdInBlocks;
+}
+
+void CUDASceneRepChunkGrid::streamInFinish()
+{
+    if (!m_streamInLock.owns_lock()) throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamInFinish without streamInWait");
+    try {
+        streamInLaunches();
+    } catch (...) {
+        m_streamInLock.unlock();
+        hEventInProduce.set();
+        throw;
+    }
+    m_streamInLock.unlock();
+    hEventInProduce.set();
+}
+
 // DSC/CUDASceneRepChunkGrid.cpp:107-124
 void CUDASceneRepChunkGrid::streamOutToCPUPass1CPU(bool multiThreaded)
 {
@@ -561,16 +646,25 @@ void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
         hEventInConsume.wait();
         lock.lock();
     }
+    try {
+        streamInLaunches();
+    } catch (...) {
+        if (multiThreaded) hEventInProduce.set();
+        throw;
+    }
+    if (multiThreaded) hEventInProduce.set();
+}
+
+// the device side of a stream-in pass the worker (or streamInToGPUPass0CPU) has prepared
+void CUDASceneRepChunkGrid::streamInLaunches()
+{
     if (s_nStreamdInBlocks != 0) {
         const HashParams& hp = m_sceneRepHashSDF->getHashParams();
         HashData& hd = m_sceneRepHashSDF->getHashData();
         vhStream_t stream = m_sceneRepHashSDF->getStream();
         unsigned int heapCountPrev = 0; // index of the top free block
         readBack(hd.d_heapCounter, nullptr, &heapCountPrev, nullptr);
-        if (s_nStreamdInBlocks > heapCountPrev + 1u) {
-            if (multiThreaded) hEventInProduce.set();
-            throw vh::Error(VH_ERR_HEAP_EXHAUSTED, "stream-in: not enough free SDF blocks");
-        }
+        if (s_nStreamdInBlocks > heapCountPrev + 1u) throw vh::Error(VH_ERR_HEAP_EXHAUSTED, "stream-in: not enough free SDF blocks");
         const int32_t token = m_sceneRepHashSDF->nextLockToken();
         m_sceneRepHashSDF->noteTableEdited();
         hipStream_t hs = (hipStream_t)stream;
@@ -584,7 +678,6 @@ void CUDASceneRepChunkGrid::streamInToGPUPass1GPU(bool multiThreaded)
         readBack(d_insertFailed, nullptr, &nFailed, nullptr); // (also: the copy above has read h_counter[0] by then)
         if (nFailed != 0) takeBackFailedInserts(nFailed, heapCountPrev);
     }
-    if (multiThreaded) hEventInProduce.set();
 }
 
 // Blocks of the last stream-in pass that found no slot (their bucket and its list full, or a second overflow of one

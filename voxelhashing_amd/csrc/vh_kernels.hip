@@ -3021,6 +3021,35 @@ __global__ __launch_bounds__(64) void k_stream_out_pass1(VhHashData hd, VhHashPa
     }
 }
 
+// The same scan without the deletes: how many blocks of the part would the pass move out?  (A frame loop that knows its
+// poses ahead asks this a frame early -- after that frame's alloc, the last pass that adds blocks -- and keeps the
+// whole streaming step out of the next frame's launches when the answer is none: Reconstruction::frame.)
+__global__ __launch_bounds__(256) void k_stream_out_probe(VhHashData hd, VhHashParams hp, uint32_t start, uint32_t n, float radius,
+                                                          float cx, float cy, float cz, uint32_t* counter)
+{
+    const uint32_t ne = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, idx = t + start;
+    bool would = false;
+    if (t < n && idx < ne) {
+        const int4 q = load_quad(&hd.d_hash[idx]);
+        const F3 pw = block_to_world(hp.m_virtualVoxelSize, mki3(q.x, q.y, q.z));
+        const F3 df = mk3(pw.x - cx, pw.y - cy, pw.z - cz);
+        would = q.w != VH_FREE_ENTRY && sqrtf(dot3(df, df)) >= radius;
+    }
+    const unsigned long long m = __ballot(would);
+    if (m != 0ull && lane_id() == 0u) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+
+// {*src, tag} into mapped host memory like k_publish_words, and the device word back to zero for the next use
+__global__ void k_publish_and_clear(uint32_t* src, uint32_t* mapped, uint32_t tag)
+{
+    mapped[0] = *src;
+    mapped[1] = 0u;
+    *src = 0u;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(&mapped[2], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // integrateFromGlobalHashPass2Kernel :97-113 (copy block out, clear source)
 __global__ __launch_bounds__(256) void k_stream_out_pass2(VhHashData hd, const VhSDFBlockDesc* descs, VhVoxel* out, uint32_t n)
 {
@@ -3674,6 +3703,16 @@ int vh_stream_out_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t t
     if (threadsPerPart == 0) return VH_OK; // DSC/CUDASceneRepChunkGrid.cu:81
     k_stream_out_pass1<<<cdiv(threadsPerPart, 64), 64, 0, (hipStream_t)stream>>>(*hd, *hp, start, radius, camPos[0], camPos[1], camPos[2],
                                                                                    d_outputCounter, d_output, outputCapacity, lockToken);
+    return vh_last_launch_error();
+}
+
+int vh_stream_out_probe(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start, float radius,
+                        const float camPos[3], uint32_t* d_counter, uint32_t* d_mapped, uint32_t tag, vhStream_t stream)
+{
+    if (!hd || !hp || !camPos || !d_counter || !d_mapped) return VH_ERR_BAD_ARGUMENT;
+    if (threadsPerPart != 0)
+        k_stream_out_probe<<<cdiv(threadsPerPart, 256), 256, 0, (hipStream_t)stream>>>(*hd, *hp, start, threadsPerPart, radius, camPos[0], camPos[1], camPos[2], d_counter);
+    k_publish_and_clear<<<1, 1, 0, (hipStream_t)stream>>>(d_counter, d_mapped, tag);
     return vh_last_launch_error();
 }
 

@@ -84,6 +84,8 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
         m_slotSceneFrame[i] = 0;
     }
     m_uploads = 0;
+    m_probePending = false;
+    std::memset(m_probePose, 0, sizeof(m_probePose));
     if (m_opt.s_framesOnHost) {
         const size_t n = (size_t)cp.m_imageWidth * cp.m_imageHeight;
         hipStream_t cs = nullptr;
@@ -135,6 +137,7 @@ void Reconstruction::reset()
     std::memset(&m_stats, 0, sizeof(m_stats));
     m_stats.uploadBytes = bytes;
     m_frameNumber = 0;
+    m_probePending = false;
     for (int i = 0; i < kStagingSlots; i++) m_slotSceneFrame[i] = 0;
 }
 
@@ -230,12 +233,16 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
     return cam;
 }
 
-void Reconstruction::frame(const SequenceFrame& f)
+namespace {
+bool poseValid(const float* m) { return !(m[0] == -std::numeric_limits<float>::infinity() || std::isnan(m[0])); }
+}
+
+void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
 {
     // :733-747
     vh::mat4f transformation;
     std::memcpy(transformation.m, f.rigidTransform, sizeof(transformation.m));
-    if (transformation.m[0] == -std::numeric_limits<float>::infinity() || std::isnan(transformation.m[0])) {
+    if (!poseValid(transformation.m)) {
         m_stats.invalidFrames++;
         return; // "INVALID FRAME"
     }
@@ -250,43 +257,83 @@ void Reconstruction::frame(const SequenceFrame& f)
     }
 
     const bool streaming = m_opt.s_streamingEnabled && m_chunkGrid;
-    const bool ahead = m_opt.s_allocAhead && m_opt.s_integrationEnabled && !streaming;
+    const bool threaded = streaming && !m_opt.s_offlineProcessing && !m_chunkGrid->getTerminatedThread();
+    const vh::vec3f p = transformation.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
+
+    // The streaming step of this frame (:881-900), decided ahead where that is possible.  The reference runs it between
+    // the ray cast of the previous pose and this frame's alloc, and blocks on two counters in it; alloc could therefore
+    // not ride in the ray caster's launch.  But in most frames nothing streams, and whether anything will is known
+    // early: the previous frame has asked the device (a count-only run of the stream-out scan for THIS frame's sphere
+    // and part, after its own alloc -- nothing adds blocks between there and here, so the count can only be too large),
+    // and what comes in is the worker thread's business on the host.  With nothing going out, nothing coming in and
+    // an unchanged bit mask the step is a no-op, and the frame runs as it does without streaming: three launches.
+    enum Step { kFull, kAfterOut, kNothing } step = kFull;
+    unsigned int nIn = 0;
+    if (threaded && m_probePending && std::memcmp(m_probePose, f.rigidTransform, sizeof(m_probePose)) == 0) {
+        const double t0 = now();
+        if (m_chunkGrid->probeResult() == 0) {
+            m_chunkGrid->streamOutNothing(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts);
+            nIn = m_chunkGrid->streamInWait();
+            step = (nIn == 0 && !m_chunkGrid->bitMaskDirty()) ? kNothing : kAfterOut;
+            if (step == kNothing) {
+                m_chunkGrid->streamInFinish(); // (launches nothing; hands the buffers back to the worker)
+                m_stats.streamingStepsSkipped++;
+            }
+        }
+        m_stats.hostWaitSeconds += now() - t0;
+    }
+    m_probePending = false;
+
+    const bool ahead = m_opt.s_allocAhead && m_opt.s_integrationEnabled && (!streaming || step == kNothing);
+    const unsigned int* d_bitMask = nullptr;
+    if (streaming && step == kNothing) d_bitMask = m_chunkGrid->getBitMaskGPU(); // (clean: no upload)
     // :750-751 (the pose the scene holds is the previous frame's)
     const vh::mat4f renderTransform = m_sceneRep->getLastRigidTransform();
     VhFrameJob* job = nullptr;
-    if (ahead) job = m_sceneRep->integrateAhead(transformation, cam, m_cp, nullptr);
+    if (ahead) job = m_sceneRep->integrateAhead(transformation, cam, m_cp, d_bitMask);
     if (m_frameNumber > 0 && m_opt.s_renderEnabled) // :750 "getFrameNumber() > 1" with frames counted from 1
         m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform, job); // :763
 
-    const unsigned int* d_bitMask = nullptr;
-    if (streaming) { // :881-900
+    if (streaming && step != kNothing) { // :881-900
         const double t0 = now();
-        const vh::vec3f p = transformation.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
         unsigned int nStreamedBlocks = 0;
-        if (m_opt.s_offlineProcessing) {
+        if (step == kAfterOut) {
+            m_chunkGrid->streamInFinish();
+            m_stats.blocksStreamedIn += nIn;
+        } else if (m_opt.s_offlineProcessing) {
             for (unsigned int i = 0; i < m_sceneRep->getOptions().s_streamingOutParts; i++) {
                 m_chunkGrid->streamOutToCPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
                 m_stats.blocksStreamedOut += nStreamedBlocks;
             }
             m_chunkGrid->streamInToGPUAll(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
             m_stats.blocksStreamedIn += nStreamedBlocks;
+        } else if (threaded) {
+            m_chunkGrid->streamOutToCPUPass0GPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, true);
+            m_stats.blocksStreamedOut += m_chunkGrid->getNumStreamedOutBlocks();
+            m_chunkGrid->streamInToGPUPass1GPU(true);
+            m_stats.blocksStreamedIn += m_chunkGrid->getNumStreamedInBlocks();
         } else {
-            const bool threaded = !m_chunkGrid->getTerminatedThread();
-            if (threaded) {
-                m_chunkGrid->streamOutToCPUPass0GPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, true);
-                m_stats.blocksStreamedOut += m_chunkGrid->getNumStreamedOutBlocks();
-                m_chunkGrid->streamInToGPUPass1GPU(true);
-                m_stats.blocksStreamedIn += m_chunkGrid->getNumStreamedInBlocks();
-            } else {
-                m_chunkGrid->streamOutToCPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
-                m_stats.blocksStreamedOut += nStreamedBlocks;
-                m_chunkGrid->streamInToGPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
-                m_stats.blocksStreamedIn += nStreamedBlocks;
-            }
+            m_chunkGrid->streamOutToCPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
+            m_stats.blocksStreamedOut += nStreamedBlocks;
+            m_chunkGrid->streamInToGPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
+            m_stats.blocksStreamedIn += nStreamedBlocks;
         }
         d_bitMask = m_chunkGrid->getBitMaskGPU();
         m_stats.hostWaitSeconds += now() - t0; // read-backs of the streaming counters: the host waits for the device here
     }
+
+    // the question for the next frame, behind this frame's alloc
+    const bool ask = threaded && m_opt.s_allocAhead && m_opt.s_integrationEnabled && next && next->depth && poseValid(next->rigidTransform);
+    auto askNow = [&]() {
+        vh::mat4f nt;
+        std::memcpy(nt.m, next->rigidTransform, sizeof(nt.m));
+        const vh::vec3f np = nt.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
+        m_chunkGrid->probeStreamOut(np, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts);
+        std::memcpy(m_probePose, next->rigidTransform, sizeof(m_probePose));
+        m_probePending = true;
+    };
+    const bool allocIsIn = ahead && job && job->allocLaunched; // (it rode in the ray caster's launch)
+    if (ask && allocIsIn) askNow();
 
     if (m_opt.s_integrationEnabled) { // :903
         if (ahead) m_sceneRep->integrateFinish(cam, m_cp);
@@ -294,6 +341,7 @@ void Reconstruction::frame(const SequenceFrame& f)
     } else {
         m_sceneRep->setLastRigidTransformAndCompactify(transformation, m_cp); // :907
     }
+    if (ask && !allocIsIn) askNow();
     m_frameNumber++;
     m_stats.frames++;
 }
@@ -317,7 +365,7 @@ void Reconstruction::run(const SequenceFrame* frames, unsigned int n)
             }
             waited += now() - w0;
         }
-        frame(frames[i]);
+        frame(frames[i], i + 1 < n ? &frames[i + 1] : nullptr);
     }
     const double total = now() - t0, streamWait = m_stats.hostWaitSeconds - streamWait0;
     m_stats.hostWaitSeconds += waited;

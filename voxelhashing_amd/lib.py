@@ -69,6 +69,7 @@ PROTOTYPES = {
     "vh_debug_check_fast_math": (C.c_int, [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _VP, _VP]),
     "vh_debug_check_refined_division": (C.c_int, [C.c_uint32, C.c_uint32, _VP, _VP]),
     "vh_publish_words": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP]),
+    "vh_stream_out_probe": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_float, _VP, _VP, _VP, C.c_uint32, _VP]),
     "vh_scene_rep_create": (C.c_int, [P(T.HashParams), P(T.SceneOptions), _VP, P(_VP)]),
     "vh_scene_rep_destroy": (None, [_VP]),
     "vh_scene_rep_integrate": (C.c_int, [_VP, _F16, P(T.DepthCameraData), P(T.DepthCameraParams), _VP]),

@@ -253,6 +253,7 @@ class ReconstructionStats(C.Structure):
         ("uploadMs", C.c_double),
         ("uploadsTimed", C.c_uint64),
         ("uploadBytes", C.c_uint64),
+        ("streamingStepsSkipped", C.c_uint64),
     ]
 
 
