@@ -1892,6 +1892,18 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
         half = e.y == phase ? (e.x >> 24) : 0u;
     }
     if (tile >= nTiles) return;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 41 // measurement build: every wave's life, read by tools/render_stamps.py
+    const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t stamp1 = 0u;
+    uint4* const stampAt = reinterpret_cast<uint4*>(hd.d_hashCompactified) + (hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + 2u * waveIdx;
+#define VH_WAVE_STAMP(COST)                                                                                                                     \
+    if (lane == 0) {                                                                                                                             \
+        stampAt[0] = make_uint4(stamp0, stamp1, (uint32_t)__builtin_amdgcn_s_memrealtime(), tile | (half << 24));                               \
+        stampAt[1] = make_uint4((COST), __builtin_amdgcn_s_getreg((31 << 11) | 4), __builtin_amdgcn_s_getreg((31 << 11) | 20), 0x57410000u | waveIdx); \
+    }
+#else
+#define VH_WAVE_STAMP(COST)
+#endif
     int* tab = tileTab[threadIdx.x / kWave];
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
@@ -1983,6 +1995,9 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
             tileZmax = zhi;
         }
     }
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 41
+    stamp1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
     const bool inImage = x < W && y < H;
     const size_t pix = (size_t)y * W + x;
@@ -2008,7 +2023,7 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
             if (lane == 0) mine[64u * 8u] = (int)cost;
         }
         __syncthreads(); // all four waves of this workgroup are halves of split tiles (schedule_tiles)
-        if (half == 2u) return;
+        if (half == 2u) { VH_WAVE_STAMP(cost) return; }
         if (!out.hit && other[lane * 8u + 0u] != 0) {
             out.hit = true;
             out.alpha = __int_as_float(other[lane * 8u + 1u]);
@@ -2022,8 +2037,10 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
         store_ray(rd, cp, pix, x, y, out, GRADIENTS);
         VH_STAT_STORE
     }
+    VH_WAVE_STAMP(cost)
     if (sched && lane == 0) sched[4 + tile] = min(cost / kCostClassWidth, kCostClasses - 1u); // plain store: nobody waits for it
 }
+#undef VH_WAVE_STAMP
 #undef VH_STAT_DECL
 #undef VH_STAT_ARGS
 #undef VH_STAT_STORE
