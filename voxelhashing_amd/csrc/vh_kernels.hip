@@ -1066,11 +1066,17 @@ constexpr uint32_t kCostClassWidth = 8;
 // rays (a silhouette grazing the truncation band) are the tail of the kernel.  A sample's state is the previous
 // sample's alone, so the far half starts at the last sample before the middle with nothing remembered and arrives at
 // the middle in the state the whole march would have; the near half's hit, if any, is the first along the ray.
-constexpr uint32_t kSplitTiles = 256;     // at most (even: two split tiles fill a workgroup); measured at 640x480: 64 -> 37.8 us, 256 -> 37.0, 512 -> 37.8
+#ifndef VH_SPLIT_TILES
+#define VH_SPLIT_TILES 256
+#endif
+constexpr uint32_t kSplitTiles = VH_SPLIT_TILES;     // at most (even: two split tiles fill a workgroup); measured at 640x480: 64 -> 37.8 us, 256 -> 37.0, 512 -> 37.8
 constexpr uint32_t kSplitMinTiles = 1024; // smaller images are not split
 __host__ __device__ inline uint32_t split_tiles(uint32_t nTiles) // one tile in sixteen, dearest first
 {
-    const uint32_t n = (nTiles / 16u) & ~1u;
+#ifndef VH_SPLIT_DIV
+#define VH_SPLIT_DIV 16
+#endif
+    const uint32_t n = (nTiles / VH_SPLIT_DIV) & ~1u;
     return nTiles >= kSplitMinTiles ? (n < kSplitTiles ? n : kSplitTiles) : 0u;
 }
 
