@@ -265,6 +265,8 @@ typedef struct VhReconstructionStats {
     uint64_t uploadsTimed;
     uint64_t uploadBytes;        /* bytes per frame upload */
     uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to be a no-op and ran with three launches */
+    uint64_t heapUnderflows;     /* the scene's status words as get_stats() found them (VH_STATE_*): alloc requests that found */
+    uint64_t failedInserts;      /* the voxel pool empty; stream-in inserts that found no slot (the blocks went back to the host grid) */
 } VhReconstructionStats;
 
 /* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt

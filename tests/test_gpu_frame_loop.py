@@ -224,6 +224,23 @@ def test_frames_without_colour_integrate_nothing(E, oracle_lib):
     assert (scene.state()["voxels"]["weight"] > 0).sum() > 100
 
 
+def test_an_empty_voxel_pool_is_reported_by_the_loop(E):
+    """a pool of 64 blocks for a frame that wants 150: the device raises VH_STATE_HEAP_UNDERFLOW, hands out no block it does
+    not have, and the loop's statistics show the count (nothing else tells a caller of vh_reconstruction_run)"""
+    hp, cp, rp = small_config(160, 120, num_sdf_blocks=64)
+    poses = [shifted_pose(k, 60) for k in range(3)]
+    scene, ray = E.CUDASceneRepHashSDF(hp, T.make_scene_options(offline=False, gc=False)), E.CUDARayCastSDF(rp)
+    recon = E.Reconstruction(scene, ray, None, cp)
+    frames = [E.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+    recon.run(seq)
+    recon.synchronize()
+    st = recon.getStats()
+    assert st["frames"] == 3 and st["heapUnderflows"] > 0 and st["failedInserts"] == 0, st
+    s = scene.state()  # (the table's invariants hold: no block is both free and allocated)
+    assert s["num_occupied"] <= 64 and s["heap_free"] == 64 - s["num_occupied"]
+
+
 def test_invalid_pose_is_skipped_and_loop_can_restart(E, oracle_lib):
     """DSC/DepthSensing.cpp:738-741: a frame whose recorded pose starts with -inf / NaN is not processed"""
     O = oracle_lib

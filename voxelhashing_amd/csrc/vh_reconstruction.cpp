@@ -153,6 +153,12 @@ const ReconstructionStats& Reconstruction::getStats()
         }
         m_uploadTimers.clear();
     }
+    // the scene's status words: an empty voxel pool or a failed stream-in insert is raised on the device; this is where a
+    // caller of the loop gets to see it (a blocking 64-byte read-back: get_stats() is not for the inside of a timed region)
+    uint32_t state[VH_STATE_WORDS];
+    m_sceneRep->getState(state);
+    m_stats.heapUnderflows = state[VH_STATE_HEAP_UNDERFLOW];
+    m_stats.failedInserts = state[VH_STATE_INSERT_FAILED];
     return m_stats;
 }
 

@@ -254,6 +254,8 @@ class ReconstructionStats(C.Structure):
         ("uploadsTimed", C.c_uint64),
         ("uploadBytes", C.c_uint64),
         ("streamingStepsSkipped", C.c_uint64),
+        ("heapUnderflows", C.c_uint64),
+        ("failedInserts", C.c_uint64),
     ]
 
 
