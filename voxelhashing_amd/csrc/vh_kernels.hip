@@ -1084,13 +1084,22 @@ __host__ __device__ inline uint32_t split_tiles(uint32_t nTiles) // one tile in 
 // class the previous k_render stored, dearest first, dealt to the workgroups (4 tiles each) in rows of numCUs that
 // alternate direction.  The hardware places workgroup g on compute unit g mod numCUs (all of them are resident), so
 // a compute unit receives one workgroup of every row: the dearest of one row with the cheapest of the next.
-__device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t* sCount /*[2 * 256]*/)
+// The sort was ONE workgroup's and the longest chain of its launch (per-workgroup time stamps, tools/riders_stamps.py: it
+// ended at 8.4 us of a 9.9 us launch at 640x480, at 50 of 50 us at 1920x1080, everything else long done).  Now kSchedGroups
+// workgroups sort a share of the tiles each -- the quads of four tiles q = part (mod parts): shares that look alike --
+// and deal their sorted shares into the launch order in turns (the tile of rank i in share w comes after rank i of the
+// shares before it): the dearest first as before, to within the difference between the shares.
+constexpr uint32_t kSchedGroups = 8;
+__host__ __device__ inline uint32_t sched_groups(uint32_t nTiles) { return nTiles >= kSplitMinTiles ? kSchedGroups : 1u; }
+
+__device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTiles, uint32_t phase, uint32_t numCUs, uint32_t part, uint32_t parts,
+                               uint32_t* sCount /*[2 * 256]*/)
 {
     // layout: {phase the slots were made for, -, -, -}, cost class per tile, {tile, phase} per launch slot
     const uint32_t* cls = sched + 4;
     uint2* slots = reinterpret_cast<uint2*>(sched + 4 + 4u * ((nTiles + 3u) / 4u));
     const uint32_t nSplit = split_tiles(nTiles);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && part == 0u) {
         sched[0] = phase;
         if (feedback) *feedback = sched[1]; // longest tile list the previous k_render met (0: none near the small capacity)
         sched[1] = 0u;
@@ -1105,16 +1114,24 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
     constexpr uint32_t kBatch = 5;
     const uint32_t nQuads = (nTiles + 3u) / 4u; // the cost array is padded to whole quads (vh_render_schedule_bytes)
     const uint4* cls4 = reinterpret_cast<const uint4*>(cls);
-    for (uint32_t q0 = threadIdx.x; q0 < nQuads; q0 += blockDim.x * kBatch) {
+    const uint32_t myQuads = part < nQuads ? (nQuads - part + parts - 1u) / parts : 0u; // quads part, part + parts, ...
+    // tiles in each share (the image's last quad may be short), for the turn-taking below
+    uint32_t nShare[kSchedGroups];
+#pragma unroll
+    for (uint32_t w = 0; w < kSchedGroups; w++) {
+        const uint32_t nq = (w < parts && w < nQuads) ? (nQuads - w + parts - 1u) / parts : 0u;
+        nShare[w] = 4u * nq - ((nq != 0u && (nQuads - 1u) % parts == w) ? 4u * nQuads - nTiles : 0u);
+    }
+    for (uint32_t q0 = threadIdx.x; q0 < myQuads; q0 += blockDim.x * kBatch) {
         uint4 c[kBatch];
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t q = q0 + j * blockDim.x;
-            c[j] = q < nQuads ? cls4[q] : make_uint4(0u, 0u, 0u, 0u);
+            c[j] = q < myQuads ? cls4[q * parts + part] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
-            const uint32_t t = (q0 + j * blockDim.x) * 4u;
+            const uint32_t t = ((q0 + j * blockDim.x) * parts + part) * 4u;
             if (t + 0u < nTiles) atomicAdd(&sCount[min(c[j].x, kCostClasses - 1u) * kSub + sub], 1u);
             if (t + 1u < nTiles) atomicAdd(&sCount[min(c[j].y, kCostClasses - 1u) * kSub + sub], 1u);
             if (t + 2u < nTiles) atomicAdd(&sCount[min(c[j].z, kCostClasses - 1u) * kSub + sub], 1u);
@@ -1140,21 +1157,25 @@ __device__ void schedule_tiles(uint32_t* sched, uint32_t* feedback, uint32_t nTi
     __syncthreads();
     // launch slots: the nSplit dearest tiles take two each (near half, far half; two tiles to a workgroup), the others one
     const uint32_t nGroups = (nTiles + nSplit + 3u) / 4u, fullRows = nGroups / numCUs;
-    for (uint32_t q0 = threadIdx.x; q0 < nQuads; q0 += blockDim.x * kBatch) {
+    for (uint32_t q0 = threadIdx.x; q0 < myQuads; q0 += blockDim.x * kBatch) {
         uint4 c[kBatch];
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t q = q0 + j * blockDim.x;
-            c[j] = q < nQuads ? cls4[q] : make_uint4(0u, 0u, 0u, 0u);
+            c[j] = q < myQuads ? cls4[q * parts + part] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t cc[4] = { c[j].x, c[j].y, c[j].z, c[j].w };
 #pragma unroll
             for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t t = (q0 + j * blockDim.x) * 4u + k;
+                const uint32_t t = ((q0 + j * blockDim.x) * parts + part) * 4u + k;
                 if (t < nTiles) {
-                    const uint32_t i = atomicAdd(&sCount[kBins + min(cc[k], kCostClasses - 1u) * kSub + sub], 1u); // rank of tile t
+                    const uint32_t mine = atomicAdd(&sCount[kBins + min(cc[k], kCostClasses - 1u) * kSub + sub], 1u); // rank of tile t in this share
+                    // its rank overall: the shares take turns, a share that has run out is skipped
+                    uint32_t i = 0u;
+#pragma unroll
+                    for (uint32_t w = 0; w < kSchedGroups; w++) i += min(mine, nShare[w]) + ((w < part && nShare[w] > mine) ? 1u : 0u);
                     if (i < nSplit) {
                         const uint32_t at = (i / 2u) * 4u + (i & 1u) * 2u;
                         slots[at] = make_uint2(t | (1u << 24), phase);
@@ -1197,8 +1218,8 @@ __device__ void interval_splat_group(const VhHashData& hd, const VhHashParams& h
     // voxel on top covers every rounding on the way (|p/vs| < 2^16 where the quotient is resolved to 2^-8).
     const float growLo = (rp.m_useGradients ? 1.75f : 1.25f) * vs, growHi = (rp.m_useGradients ? 0.75f : 0.25f) * vs;
 
-    if (group >= nSplatGroups) { // the extra workgroup (launched only with a schedule)
-        schedule_tiles(sched, feedback, (uint32_t)(tilesX * tilesY), phase, numCUs, sBuckets);
+    if (group >= nSplatGroups) { // the extra workgroups (launched only with a schedule)
+        schedule_tiles(sched, feedback, (uint32_t)(tilesX * tilesY), phase, numCUs, group - nSplatGroups, sched_groups((uint32_t)(tilesX * tilesY)), sBuckets);
         return;
     }
     if (threadIdx.x == 0) { sNumBuckets = 0u; sNumBlocks = 0u; }
@@ -2126,7 +2147,7 @@ struct CoSplat {
     uint32_t* sched;
     uint32_t* feedback;
     uint32_t cap, phase, numCUs, nSplatGroups;
-    uint32_t groups; // nSplatGroups (+ 1 with a schedule); 0: nothing to co-launch
+    uint32_t groups; // nSplatGroups (+ sched_groups() with a schedule); 0: nothing to co-launch
 };
 
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
@@ -2135,8 +2156,15 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
     __shared__ union RiderShared { SplatShared splat; CompactShared compact; } shared;
     SplatShared& sh = shared.splat;
     uint32_t g = blockIdx.x;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42 // measurement build: every workgroup's life by kind, read by tools/riders_stamps.py
+    const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint4* const stampAt = reinterpret_cast<uint4*>(job.hd.d_hashCompactified) + (job.hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + blockIdx.x;
+#define VH_GROUP_STAMP(KIND) { __syncthreads(); if (threadIdx.x == 0) *stampAt = make_uint4(stamp0, (uint32_t)__builtin_amdgcn_s_memrealtime(), (KIND), 0x5742u); }
+#else
+#define VH_GROUP_STAMP(KIND)
+#endif
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 31 // measurement builds: the riders of this launch, one at a time
-    if (g == 0u && splat.groups > splat.nSplatGroups) return; // no schedule workgroup
+    if (g < splat.groups - splat.nSplatGroups) return; // no schedule workgroups
 #elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 32
     if (g < splat.groups) return; // no splat at all
 #elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 33
@@ -2145,21 +2173,28 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
     if (g >= splat.groups + job.groups) return; // no normals
 #endif
     if (g < splat.groups) {
-        // the schedule workgroup first (one workgroup sorts all tiles: the longest chain), then the table's slices
-        const bool withSchedule = splat.groups > splat.nSplatGroups;
-        const uint32_t group = withSchedule ? (g == 0u ? splat.nSplatGroups : g - 1u) : g;
+        // the schedule workgroups first (the longest chains), then the table's slices
+        const uint32_t nSched = splat.groups - splat.nSplatGroups;
+        const uint32_t group = g < nSched ? splat.nSplatGroups + g : g - nSched;
         interval_splat_group(job.hd, job.hp, splat.cp, splat.rp, splat.heads, splat.lists, splat.cap, splat.sched, splat.phase, splat.numCUs,
                              splat.nSplatGroups, splat.feedback, group, sh);
+        VH_GROUP_STAMP(group >= splat.nSplatGroups ? 1u : 2u)
         return;
     }
     g -= splat.groups;
     if (g < job.groups) {
         compactify_group(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
+        VH_GROUP_STAMP(3u)
         return;
     }
     g -= job.groups;
     const uint32_t idx = g * blockDim.x + threadIdx.x;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
+    if (job.groups != 0u && idx < width * height) {
+#else
     if (idx >= width * height) return;
+    {
+#endif
     const uint32_t x = idx % width, y = idx / width;
     const float mi = minf();
     float4 o = make_float4(mi, mi, mi, mi);
@@ -2173,7 +2208,12 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
         }
     }
     out[idx] = o;
+    }
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
+    if (job.groups != 0u) VH_GROUP_STAMP(4u)
+#endif
 }
+#undef VH_GROUP_STAMP
 
 // ---------------------------------------------------------------------------
 // marching cubes (DSC/CUDAMarchingCubesSDF.cu:65-143, DSC/MarchingCubesSDFUtil.h:154-311)
@@ -3494,7 +3534,8 @@ int vh_ray_interval_splat(const VhHashData* hd, const VhHashParams* hp, const Vh
     const uint32_t numCUs = d_schedule ? device_num_cus() : 256u;
     const uint32_t nWords = (hp->m_hashNumBuckets + 31) / 32;
     const uint32_t groups = cdiv(nWords, kSplatWordsPerGroup);
-    k_interval_splat<<<groups + (d_schedule ? 1u : 0u), 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
+    const uint32_t nSched = d_schedule ? sched_groups(cdiv(rp->m_width, 8) * cdiv(rp->m_height, 8)) : 0u;
+    k_interval_splat<<<groups + nSched, 256, 0, (hipStream_t)stream>>>(*hd, *hp, *cp, *rp, reinterpret_cast<uint4*>(d_tileHeads),
                                                                                  reinterpret_cast<int4*>(d_tileBlocks), d_tileBlocks ? tileCapacity : 0u,
                                                                                  d_schedule, phase, numCUs, groups, d_longestList);
     return vh_last_launch_error();
@@ -3525,7 +3566,7 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
             sp.phase = phase;
             sp.numCUs = d_schedule ? device_num_cus() : 256u;
             sp.nSplatGroups = cdiv((fj->hashParams.m_hashNumBuckets + 31) / 32, kSplatWordsPerGroup);
-            sp.groups = sp.nSplatGroups + (d_schedule ? 1u : 0u);
+            sp.groups = sp.nSplatGroups + (d_schedule ? sched_groups(cdiv(nextView->m_width, 8) * cdiv(nextView->m_height, 8)) : 0u);
             groups += sp.groups;
         }
     }
