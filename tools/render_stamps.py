@@ -9,7 +9,7 @@ import numpy as np
 def main():
     import torch
     from voxelhashing_amd import engine as E, lib, synth, vhtypes as T
-    cfg = dict(synth.CONFIGS["cfg2"])
+    cfg = dict(synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"])
     hp, cp, rp = synth.config_params(cfg)
     spheres, inside, radius = synth.scene(cfg["scene"])
     scene, ray = E.CUDASceneRepHashSDF(hp, T.make_scene_options(offline=False, gc=True, starve=15)), E.CUDARayCastSDF(rp)
@@ -22,7 +22,7 @@ def main():
     recon.synchronize()
     hd, hpp = scene.getHashData(), scene.getHashParams()
     ne = hpp.m_hashNumBuckets * T.HASH_BUCKET_SIZE
-    nw = 4 * 1400
+    nw = 4 * 9000
     raw = lib.download(hd.d_hashCompactified + 16 * (ne // 2), np.uint32, 8 * nw).reshape(nw, 8)
     ok = (raw[:, 7] >> 16) == 0x5741
     raw = raw[ok]
