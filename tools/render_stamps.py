@@ -23,7 +23,7 @@ def main():
     hd, hpp = scene.getHashData(), scene.getHashParams()
     ne = hpp.m_hashNumBuckets * T.HASH_BUCKET_SIZE
     nw = 4 * 9000
-    raw = lib.download(hd.d_hashCompactified + 16 * (ne // 2), np.uint32, 8 * nw).reshape(nw, 8)
+    raw = lib.download(hd.d_hashCompactified + 16 * (ne // 2), np.uint32, 12 * nw).reshape(nw, 12)
     ok = (raw[:, 7] >> 16) == 0x5741
     raw = raw[ok]
     t0 = int(raw[:, 0].min())
@@ -44,6 +44,20 @@ def main():
     out["simds"] = len(u)
     late = np.argsort(en)[-12:]
     out["latest_waves"] = [dict(end=round(float(en[i]), 2), start=round(float(st[i]), 2), built=round(float(built[i] - st[i]), 2), half=int(half[i]), cost=int(cost[i])) for i in late]
+    listlen = (raw[:, 8] & 0xffff).astype(np.float64)
+    incomplete = ((raw[:, 8] >> 16) & 1).astype(np.float64)
+    out["list_length"] = q(listlen)
+    out["incomplete_tables"] = int(incomplete.sum())
+    # what predicts a SIMD's finishing time?  least squares over the SIMDs
+    X = np.stack([np.bincount(inv, weights=cost.astype(np.float64)), np.bincount(inv, weights=listlen), np.bincount(inv, weights=incomplete),
+                  np.bincount(inv, weights=(built - st)), np.ones(len(u))], axis=1)
+    coef, res, rk, sv = np.linalg.lstsq(X, endmax, rcond=None)
+    pred = X @ coef
+    out["fit_end_us"] = dict(per_cost=round(float(coef[0]), 4), per_list_entry=round(float(coef[1]), 4), per_incomplete=round(float(coef[2]), 3),
+                             per_us_of_table_build=round(float(coef[3]), 3), const=round(float(coef[4]), 2),
+                             r=round(float(np.corrcoef(pred, endmax)[0, 1]), 3),
+                             r_cost_only=round(float(np.corrcoef(X[:, 0], endmax)[0, 1]), 3), r_list_only=round(float(np.corrcoef(X[:, 1], endmax)[0, 1]), 3),
+                             r_build_only=round(float(np.corrcoef(X[:, 3], endmax)[0, 1]), 3))
     nw_s = np.bincount(inv)
     sumcost = np.bincount(inv, weights=cost.astype(np.float64))
     out["waves_per_simd"] = np.bincount(nw_s).tolist()

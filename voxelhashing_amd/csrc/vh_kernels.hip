@@ -1922,11 +1922,13 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 41 // measurement build: every wave's life, read by tools/render_stamps.py
     const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
     uint32_t stamp1 = 0u;
-    uint4* const stampAt = reinterpret_cast<uint4*>(hd.d_hashCompactified) + (hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + 2u * waveIdx;
+    uint4* const stampAt = reinterpret_cast<uint4*>(hd.d_hashCompactified) + (hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + 3u * waveIdx;
+    uint32_t stampList = 0u;
 #define VH_WAVE_STAMP(COST)                                                                                                                     \
     if (lane == 0) {                                                                                                                             \
         stampAt[0] = make_uint4(stamp0, stamp1, (uint32_t)__builtin_amdgcn_s_memrealtime(), tile | (half << 24));                               \
         stampAt[1] = make_uint4((COST), __builtin_amdgcn_s_getreg((31 << 11) | 4), __builtin_amdgcn_s_getreg((31 << 11) | 20), 0x57410000u | waveIdx); \
+        stampAt[2] = make_uint4(stampList, 0u, 0u, 0u);                                                                                           \
     }
 #else
 #define VH_WAVE_STAMP(COST)
@@ -1938,6 +1940,9 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     if (lane == 0 && half == 0u) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u); // (a split tile: once both halves have read it)
     const uint32_t listed = min(head.z, min(cap, CAP));
     const bool complete = listed == head.z;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 41
+    stampList = head.z | (complete ? 0u : 0x10000u);
+#endif
     // feedback for the host's choice of CAP: the longest list of the frame (only lists near the small capacity report)
     if (sched && lane == 0 && head.z > (uint32_t)VH_TILE_LIST_CAPACITY - 16u) atomicMax(&sched[1], head.z);
     for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i * kTileSlotWords + 3u] = VH_FREE_ENTRY;
