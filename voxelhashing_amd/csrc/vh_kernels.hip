@@ -761,6 +761,10 @@ void k_integrate_fused(FusedArgs args)
         // ---- one workgroup per block
         const uint32_t b = blockIdx.x;
         if (b >= count) return;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43 // measurement build: every workgroup's life in this shape, read by tools/integrate_stamps.py
+        const uint32_t stampA = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        uint32_t stampB = 0u, stampFreed = 0u;
+#endif
         const uint32_t t = threadIdx.x;
         const int ex = __builtin_amdgcn_readfirstlane(qg.x), ey = __builtin_amdgcn_readfirstlane(qg.y);
         const int ez = __builtin_amdgcn_readfirstlane(qg.z), ptr = __builtin_amdgcn_readfirstlane(qg.w);
@@ -771,6 +775,10 @@ void k_integrate_fused(FusedArgs args)
         float minSdf = pinf();
         uint32_t maxW = 0u;
         integrate_pair<PACKED>(hp, cp, cam, packed, flags, p0, raw, minSdf, maxW);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
+        asm volatile("" : "+v"(raw.x));
+        stampB = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         if (flags & VH_FUSED_GC) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -790,9 +798,15 @@ void k_integrate_fused(FusedArgs args)
                 }
                 __syncthreads();
                 if (sFreed != 0) raw = make_uint4(0u, 0u, 0u, 0u);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
+                stampFreed = 1u + (uint32_t)sFreed;
+#endif
             }
         }
         *vp = raw;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
+        if (t == 0) reinterpret_cast<uint4*>(hd.d_hashCompactified)[nEntries / 2u + b] = make_uint4(stampA, stampB, (uint32_t)__builtin_amdgcn_s_memrealtime(), 0x57430000u | stampFreed);
+#endif
         return;
     }
 
