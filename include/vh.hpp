@@ -116,6 +116,10 @@ public:
     VhFrameJob* integrateAhead(const vh::mat4f& lastRigidTransform, const DepthCameraData& depthCameraData,
                                const DepthCameraParams& depthCameraParams, const unsigned int* d_bitMask);
     void integrateFinish(const DepthCameraData& depthCameraData, const DepthCameraParams& depthCameraParams);
+    // gives up a job of integrateAhead() that will not be finished (the caller is unwinding): the scene accepts
+    // integrate() / integrateAhead() again.  Blocks an alloc pass that already ran has added stay: they are empty, and
+    // garbage collection takes them like any other unobserved block.
+    void abortAhead() { m_aheadPending = 0; }
     // frames whose pass over the voxels has started on the device (read from mapped host memory: no synchronisation)
     unsigned int getNumFramesStartedOnDevice() const;
     // whoever edits the table outside integrate() (streaming) says so: work prepared from the table before is void
@@ -183,6 +187,8 @@ public:
     // ray-interval splatting (DSC/CUDARayCastSDF.cpp:84-100, disabled in the reference fork): on by default here,
     // as a conservative compute pass that leaves every output bit unchanged
     void setIntervalSplatting(bool on) { m_useIntervals = on; }
+    // render() calls so far that ran on an interval splat made ahead (inside the previous call's computeNormals launch)
+    unsigned int getNumSplatsMadeAheadUsed() const { return m_preSplatsUsed; }
 
 private:
     RayCastParams m_params;
@@ -198,6 +204,7 @@ private:
     uint32_t m_quietFrames, m_tileCapacity;
     uint32_t* d_schedule;      // tiles by cost class, for the launch order of the next render()
     uint32_t m_phase;          // render() calls with intervals so far
+    unsigned int m_preSplatsUsed;
     bool m_useIntervals;
     // the interval splat of the next render, made ahead inside this render's computeNormals launch (vh_compute_normals_co2)
     struct PreSplat {
@@ -271,6 +278,9 @@ public:
     void streamOutNothing(const vh::vec3f& posCamera, float radius, bool useParts);
     unsigned int streamInWait();
     void streamInFinish();
+    // after streamInWait(), instead of streamInFinish(): the blocks the worker has staged go back into the host grid,
+    // nothing is launched, the worker gets its buffers and its event (for a caller that is unwinding)
+    void streamInAbort();
     bool bitMaskDirty() const { return m_bitMaskDirty; }
     unsigned int integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts);
     // blocks that stream-in passes could not insert and that went back to the host grid (not in the reference)
@@ -409,12 +419,16 @@ public:
     Reconstruction& operator=(const Reconstruction&) = delete;
 
     static ReconstructionOptions defaultOptions();
-    void run(const SequenceFrame* frames, unsigned int n);
+    // next: the frame that will follow frames[n-1] in a later call, if the caller knows it (only its pose is read)
+    void run(const SequenceFrame* frames, unsigned int n, const SequenceFrame* next = nullptr);
     void synchronize();
     void reset();
     const ReconstructionStats& getStats();
+    // test hook: the n-th ray cast from now throws instead of running (0: off) -- the loop's unwinding is tested with it
+    void debugFailRender(unsigned int nthRenderFromNow) { m_debugFailRender = nthRenderFromNow; }
 
 private:
+    unsigned int m_debugFailRender;
     void frame(const SequenceFrame& f, const SequenceFrame* next);
     bool m_probePending;        // a stream-out probe for the frame with pose m_probePose is in the stream
     float m_probePose[16];

@@ -49,6 +49,11 @@ int vh_free_host(void* hostPtr);
 int vh_memcpy_h2d(void* dst, const void* src, size_t bytes, vhStream_t stream);
 int vh_memcpy_d2h(void* dst, const void* src, size_t bytes, vhStream_t stream); /* synchronises the stream */
 int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream);
+/* measurement: the next kernel the calling thread launches through vh_render_intervals[_co], vh_compute_normals[_co, _co2] or
+ * vh_integrate_fused is launched with hipExtLaunchKernel's start / stop events (two hipEvent_t created with timing):
+ * hipEventElapsedTime(start, stop) is then that kernel's own duration -- the dispatch's begin and end time stamps, what
+ * rocprofv3's kernel trace reports -- with no event record in the stream.  The launch consumes the pair. */
+int vh_time_next_launch(void* startEvent, void* stopEvent);
 int vh_stream_create(vhStream_t* out);   /* a non-blocking HIP stream, for FFI users without a HIP binding */
 int vh_stream_destroy(vhStream_t stream);
 int vh_stream_synchronize(vhStream_t stream);
@@ -223,6 +228,11 @@ int vh_debug_check_fast_math(float divisor, uint32_t modulus, uint32_t n, uint32
  * the two perspective divisions of a voxel; the same for the blend's division by the weight sum): n pseudo-random
  * operand pairs inside the certified ranges against `/`.  d_mismatches[0]: projection range, [1]: blend range. */
 int vh_debug_check_refined_division(uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream);
+/* measurement, not part of the path: every SIMD of the device runs `wavesPerSimd` waves (1..8), each a chain-free stream of
+ * 32 * iters vector instructions (mode 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_add_u32, 3 v_mul_lo_u32); per wave
+ * {start, end in 100 MHz ticks, s_memtime ticks spent, hardware id} into d_stamps (4 words per wave, *numWaves waves: room for
+ * 8 * 4 * the device's compute units).  tools/valu_issue_probe.py turns that into cycles per wave-instruction per SIMD */
+int vh_debug_valu_probe(uint32_t mode, uint32_t wavesPerSimd, uint32_t iters, uint32_t* d_stamps, uint32_t* numWaves, vhStream_t stream);
 
 /* ---- host classes (opaque handles over the C++ classes of include/vh.hpp) ---- */
 typedef struct VhSceneRep VhSceneRep;   /* CUDASceneRepHashSDF,   DSC/CUDASceneRepHashSDF.h:28 */
@@ -336,9 +346,15 @@ int vh_reconstruction_create(VhSceneRep* scene, VhRayCast* rayCast, VhChunkGrid*
 void vh_reconstruction_destroy(VhReconstruction* r);
 /* processes frames[0..n): frame numbers continue from the previous call (the first frame of all is not ray-cast) */
 int vh_reconstruction_run(VhReconstruction* r, const VhSequenceFrame* frames, uint32_t n);
+/* the same for a caller that feeds the loop a few frames at a time and knows what comes next: `next` is the frame that
+ * will follow frames[n-1] (only its pose is read; NULL: unknown).  With streaming on, the loop then asks the device
+ * about that frame's streaming step behind the last frame's alloc pass, as it does inside a call (not in the reference) */
+int vh_reconstruction_run_ahead(VhReconstruction* r, const VhSequenceFrame* frames, uint32_t n, const VhSequenceFrame* next);
 /* waits for everything the loop has enqueued (all its streams) */
 int vh_reconstruction_synchronize(VhReconstruction* r);
 int vh_reconstruction_get_stats(VhReconstruction* r, VhReconstructionStats* out);
+/* test hook: the n-th ray cast from now fails with an error instead of running (0: off); the loop must unwind cleanly */
+int vh_reconstruction_debug_fail_render(VhReconstruction* r, uint32_t nthRenderFromNow);
 /* frame counter and statistics back to zero (the scene is the caller's to reset) */
 int vh_reconstruction_reset(VhReconstruction* r);
 

@@ -236,12 +236,14 @@ typedef struct VhReconstructionOptions {
     uint8_t s_integrationEnabled; /* :903-908: 0 = setLastRigidTransformAndCompactify instead of integrate */
     uint8_t s_offlineProcessing;  /* :885-891: streaming moves every part out and everything in range in, each frame */
     uint8_t s_renderEnabled;      /* 0 = skip the ray cast of the previous pose (:763) */
-    uint8_t s_allocAhead;         /* not in the reference: alloc + compactify of frame k run beside the ray cast of pose
-                                     k-1 (CUDASceneRepHashSDF::integrateAhead); ignored while streaming is on */
+    uint8_t s_allocAhead;         /* not in the reference: alloc of frame k rides in the launch of the ray cast of pose k-1, compactify
+                                     and the next pose's interval splat in computeNormals' (CUDASceneRepHashSDF::integrateAhead).
+                                     With streaming on: in the frames whose streaming step is known a frame ahead to be a no-op
+                                     (vh_stream_out_probe), and in frames where blocks only LEAVE (the pass runs behind the ray cast) */
     uint8_t s_framesOnHost;       /* not in the reference: VhSequenceFrame pointers are HOST memory (pinned for an
                                      asynchronous copy): float depth + RGBX bytes as a sensor delivers them
-                                     (RGBDSensor::getDepthFloat / getColorRGBX); uploaded on a copy stream into two
-                                     staging slots, beside the previous frame's work */
+                                     (RGBDSensor::getDepthFloat / getColorRGBX); uploaded by two copy streams (depth, colour) into
+                                     a ring of four staging slots, beside the previous frames' work */
     uint8_t pad0[2];
     uint32_t s_maxFramesInFlight; /* frames the host may enqueue ahead of the device (0 = no bound) */
     float s_streamingPos[3];      /* DSC/DepthSensing.cpp:1340-1355: in camera space */
@@ -261,12 +263,16 @@ typedef struct VhReconstructionStats {
     uint64_t blocksStreamedOut, blocksStreamedIn;
     double hostEnqueueSeconds;   /* host time inside run() spent enqueueing work (waits for the device excluded) */
     double hostWaitSeconds;      /* host time inside run() spent waiting: run-ahead bound, streaming read-backs */
-    double uploadMs;             /* device time of the timed frame uploads (copy stream, HIP events) */
+    double uploadMs;             /* device time of the timed frame uploads: depth copy, colour copy and conversion (HIP events; the pair
+                                    spans both copy streams) */
     uint64_t uploadsTimed;
     uint64_t uploadBytes;        /* bytes per frame upload */
     uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to be a no-op and ran with three launches */
     uint64_t heapUnderflows;     /* the scene's status words as get_stats() found them (VH_STATE_*): alloc requests that found */
     uint64_t failedInserts;      /* the voxel pool empty; stream-in inserts that found no slot (the blocks went back to the host grid) */
+    uint64_t framesWithRiders;   /* frames whose alloc pass rode in the ray caster's launch and whose compactify pass rode in computeNormals' */
+    uint64_t splatsMadeAheadUsed; /* ray casts that ran on an interval splat made ahead (inside the previous computeNormals launch): such a
+                                     frame is three launches -- k_render, k_compute_normals, k_integrate_fused */
 } VhReconstructionStats;
 
 /* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt
@@ -356,7 +362,9 @@ enum {
     VH_ERR_INSERT_FAILED = 3,
     VH_ERR_BAD_ARGUMENT = 4,
     VH_ERR_VERSION_MISMATCH = 5,
-    VH_ERR_IO = 6
+    VH_ERR_IO = 6,
+    VH_ERR_TIMEOUT = 7 /* the device made no progress for 30 s (hung or faulted): not a misuse.  Work may still be enqueued against the
+                          caller's frame buffers: synchronize() or destroy the loop before freeing them */
 };
 
 #ifdef __cplusplus

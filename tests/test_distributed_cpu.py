@@ -59,6 +59,8 @@ def test_bench_starts_its_own_ranks():
     # two ranks x 5 frames of 2 ms each, timed as the slower rank: 10 frames in >= 10 ms
     assert 0 < res["value"] <= 2 * 5 / 0.010 + 1
     assert "STANDIN" in res["data"]
+    # every rank's own rate is in the line (a slow rank must be visible, not only the maximum)
+    assert len(res["per_rank_frames_per_s"]) == 2 and all(0 < v <= 1 / 0.002 + 1 for v in res["per_rank_frames_per_s"])
 
 
 def test_a_failing_rank_fails_the_launch():
@@ -70,3 +72,25 @@ def test_a_failing_rank_fails_the_launch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0
+
+
+import pytest  # noqa: E402
+import time  # noqa: E402
+
+
+@pytest.mark.parametrize("where", ["before-init", "before-barrier"])
+def test_a_rank_that_dies_early_stops_the_launch_within_seconds(where):
+    """rank 1 gives up before the rendezvous / before the first barrier: rank 0 would sit there until the rendezvous or
+    the collective times out (minutes).  The launcher watches every child, stops the others and exits non-zero at
+    once, with the failing rank's stderr."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--standin",
+                        "--standin-fail", f"1:{where}"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    dt = time.time() - t0
+    assert p.returncode != 0
+    assert dt < 45, f"the launcher took {dt:.0f} s to notice"
+    err = p.stderr.decode()
+    assert "rank 1 of 2 exited" in err and "gives up" in err, err
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")], "no result line from a failed run"

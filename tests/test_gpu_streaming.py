@@ -233,3 +233,50 @@ def test_streaming_step_decided_ahead_changes_nothing(vh, radius):
         assert ta["blocksStreamedOut"] > 20 and 1 <= ta["streamingStepsSkipped"] < n - 5, ta
     else:  # the sphere holds the whole scene: every frame but the first of each run() call (nobody asked about that one)
         assert ta["blocksStreamedOut"] == 0 and ta["streamingStepsSkipped"] == n - 3, ta
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("radius", [RADIUS, 5.0])
+def test_a_failing_ray_cast_unwinds_the_loop(vh, radius):
+    """frame() holds two hand-offs across the ray cast: the worker's stream-in mutex (streamInWait ... streamInFinish) and
+    the scene's job (integrateAhead ... integrateFinish).  A ray cast that throws in between (injected:
+    vh_reconstruction_debug_fail_render) must leave neither behind -- stopping the worker afterwards returns instead of
+    deadlocking, the scene accepts integrate() again, no block is lost between the table and the host grid."""
+    from voxelhashing_amd import engine as E
+    hp, cp, rp = small_config(160, 120, num_buckets=1 << 15, num_sdf_blocks=1 << 13, streaming_extents=EXT, streaming_dims=DIMS, streaming_min=MINP)
+    n = 24
+    poses = [synth.orbit_pose(k, 120) for k in range(n)]
+    for nth in (1, 2, 3, 5, 8, 13):
+        opt = T.make_scene_options(offline=False, gc=True, starve=15, streaming_out_parts=PARTS)
+        scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+        grid = E.CUDASceneRepChunkGrid(scene, EXT, DIMS, MINP, 64, True, PARTS)
+        frames = [E.synth_frame(synth.S1_SPHERES, 0, p, cp) for p in poses]
+        recon = E.Reconstruction(scene, ray, grid, cp, E.Reconstruction.defaultOptions(s_streamingEnabled=1, s_streamingPos=STREAM_POS[:3], s_streamingRadius=radius,
+                                                                                      s_allocAhead=1, s_maxFramesInFlight=4))
+        seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+        recon.run(seq, 0, 4)
+        recon.debugFailRender(nth)
+        with pytest.raises(Exception, match="injected"):
+            recon.run(seq, 4, n - 4)
+        recon.synchronize()
+        done = recon.getStats()["frames"]
+        assert done == 4 + nth - 1
+        # the loop goes on where it stopped (the frame that failed is run again), and the worker is still there
+        recon.run(seq, done, n - done)
+        recon.synchronize()
+        assert recon.getStats()["frames"] == n
+        grid.debugCheckForDuplicates()
+        st = scene.getState()
+        assert st[T.STATE_HEAP_UNDERFLOW] == 0 and st[T.STATE_INSERT_FAILED] == 0
+        # a second failure, then straight to tearing everything down: stopping the worker must not deadlock
+        recon.debugFailRender(1)
+        with pytest.raises(Exception, match="injected"):
+            recon.run(seq, n - 2, 2)
+        scene.integrate(poses[0], frames[0], cp, grid.getBitMaskGPU())  # not refused: no job is pending
+        grid.reset()
+        s = scene.state()  # invariants
+        assert s["num_occupied"] > 10
+        recon.close()
+        grid.close()
+        ray.close()
+        scene.close()

@@ -1,0 +1,212 @@
+"""The code path bench.py times, at the size it times, against the oracle.
+
+bench.py's headline number is the NATIVE frame loop (vh_reconstruction_run) with online alloc and the riders on:
+three launches per frame -- the alloc pass of frame k inside k_render's launch (ray cast of pose k-1), compactify and
+the next pose's interval splat inside k_compute_normals', then k_integrate_fused.  At 640x480 that k_render launch has a
+shape no small image reaches: all 4 800 tiles resident at six waves per SIMD, the dearest tiles split between two
+waves, the alloc rider filling the tail.  The tests here put the oracle (oracle/libvh_oracle.so, bit for bit: the
+canonical scene and all four ray-cast maps) behind exactly that path:
+
+  * cfg2's tables (500 k buckets / 5 M entries), 640x480, frame by frame and in ONE run() call;
+  * one 1080p sequence with cfg4's tables (five rounds of ray-caster workgroups);
+  * cfg3's tables (2 M buckets / 20 M entries, 1 cm voxels) with streaming on and the streaming step decided a frame
+    ahead, against oracle/chunk_grid.py after every frame (a small sphere, so that blocks do leave).
+
+Order of calls per frame: DSC/DepthSensing.cpp:750-763 (render with the previous pose), :881-900 (stream out / in),
+:903 (integrate).  The scene is S1 moved away from the origin, where an ONLINE alloc pass is deterministic (asserted
+through the oracle: tests/test_gpu_frame_loop.py explains the hash's symmetry)."""
+import numpy as np
+import pytest
+
+from helpers import assert_maps_equal
+from voxelhashing_amd import canonical, synth, vhtypes as T
+
+pytestmark = pytest.mark.gpu
+
+OFFSET = np.array([7.3, 5.1, 3.7])
+SHIFTED_S1 = synth.S1_SPHERES.copy()
+SHIFTED_S1[:, :3] += OFFSET
+
+
+def shifted_pose(k, n_frames=1000):
+    q = np.array(synth.orbit_pose(k, n_frames=n_frames), dtype=np.float32).copy()
+    q[3] += np.float32(OFFSET[0])
+    q[7] += np.float32(OFFSET[1])
+    q[11] += np.float32(OFFSET[2])
+    return q
+
+
+@pytest.fixture(scope="module")
+def E(vh):
+    from voxelhashing_amd import engine
+    return engine
+
+
+def online_is_deterministic(O, hp, cp, rp, poses, host, starve):
+    on = O.OracleScene(hp, cp, rp, T.make_scene_options(offline=False, gc=True, starve=starve))
+    off = O.OracleScene(hp, cp, rp, T.make_scene_options(offline=True, gc=True, starve=starve))
+    for p, (d, c) in zip(poses, host):
+        on.integrate(p, d, c)
+        off.integrate(p, d, c)
+        if not np.array_equal(canonical.block_positions(on.hash_table()), canonical.block_positions(off.hash_table())):
+            return False
+    return True
+
+
+def timed_path_against_oracle(E, O, vh, cfg, n, pose_step, starve, n_blocks):
+    """-> statistics of the frame-by-frame run.  The loop's options are bench.py's: online alloc, s_allocAhead = 1,
+    s_maxFramesInFlight = 16, garbage collection on."""
+    c = dict(synth.CONFIGS[cfg])
+    c.update(num_sdf_blocks=n_blocks)  # the table at full size; the voxel pool sized to be downloadable
+    hp, cp, rp = synth.config_params(c)
+    n_tiles = ((cp.m_imageWidth + 7) // 8) * ((cp.m_imageHeight + 7) // 8)
+    assert n_tiles >= 1024 and vh.vh_render_split_tiles(cp.m_imageWidth, cp.m_imageHeight) > 0, "the launch must have the scheduled split-tile shape"
+    poses = [shifted_pose(k * pose_step) for k in range(n)]
+    frames = [E.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    host = [O.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    assert online_is_deterministic(O, hp, cp, rp, poses, host, starve), "pick poses without same-pass bucket sharing"
+    opt = T.make_scene_options(offline=False, gc=True, starve=starve)
+    ropt = dict(s_allocAhead=1, s_maxFramesInFlight=16)
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+
+    # ---- frame by frame: every map and every scene
+    scene, ray, ref = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp), O.OracleScene(hp, cp, rp, opt)
+    recon = E.Reconstruction(scene, ray, None, cp, E.Reconstruction.defaultOptions(**ropt))
+    hits, freed, want_last, states = 0, 0, None, []
+    for k in range(n):
+        recon.run(seq, k, 1)
+        recon.synchronize()
+        if k > 0:
+            want_last = ref.render(poses[k - 1])
+            assert_maps_equal(ray.download(), want_last, f"{cfg} frame {k}: ray cast of pose {k - 1}")
+            hits += int((want_last["depth"] != -np.inf).sum())
+        ref.integrate(poses[k], host[k][0], host[k][1])
+        want = ref.state()
+        canonical.assert_same_scene(scene.state(), want, f"{cfg} frame {k}")
+        states.append(want["num_occupied"])
+        freed += int(np.count_nonzero(ref.decisions()[: int(ref.hp.m_numOccupiedBlocks)]))  # blocks the GC pass flagged
+    st = recon.getStats()
+    assert st["frames"] == n and st["invalidFrames"] == 0
+    # the launches really had the timed shape: riders in every frame that has a ray cast, the splat made ahead used by
+    # every ray cast but the first (three launches per frame)
+    assert st["framesWithRiders"] == n - 1, st
+    assert st["splatsMadeAheadUsed"] == n - 2, st
+    sw = scene.getState()
+    assert sw[T.STATE_HEAP_UNDERFLOW] == 0 and sw[T.STATE_INSERT_FAILED] == 0
+    final = ref.state()
+    recon.close()
+    ray.close()
+    scene.close()
+
+    # ---- the same frames in ONE call: the host runs ahead of the device, nothing synchronises between the frames
+    scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+    recon = E.Reconstruction(scene, ray, None, cp, E.Reconstruction.defaultOptions(**ropt))
+    recon.run(seq, 0, n)
+    recon.synchronize()
+    assert_maps_equal(ray.download(), want_last, f"{cfg}, {n} frames in one call: the last ray cast")
+    canonical.assert_same_scene(scene.state(), final, f"{cfg}, {n} frames in one call")
+    st1 = recon.getStats()
+    assert st1["framesWithRiders"] == n - 1 and st1["splatsMadeAheadUsed"] == n - 2, st1
+    ray.render(scene.getHashData(), scene.getHashParams(), cp, poses[-1])
+    assert_maps_equal(ray.download(), ref.render(poses[-1]), f"{cfg}: render after the sequence")
+    recon.close()
+    ray.close()
+    scene.close()
+    return dict(hits=hits, freed=freed, blocks=states)
+
+
+def test_cfg2_native_loop_with_riders_at_the_timed_size(E, oracle_lib, vh):
+    """BASELINE.json configs[1] as bench.py runs it: 640x480, 4 cm voxels, 500 k buckets, native loop, online alloc,
+    riders on; ten frames, starve every third (so that the fused pass starves and frees)"""
+    r = timed_path_against_oracle(E, oracle_lib, vh, "cfg2", 10, 9, 3, 1 << 14)
+    assert r["hits"] > 500000 and min(r["blocks"]) > 100 and r["freed"] > 0, r
+
+
+@pytest.mark.slow
+def test_cfg4_native_loop_with_riders_at_1080p(E, oracle_lib, vh):
+    """BASELINE.json configs[3]: 1920x1080, 2 cm voxels -- 32 400 tiles, five rounds of ray-caster workgroups with the
+    alloc rider behind them"""
+    r = timed_path_against_oracle(E, oracle_lib, vh, "cfg4", 4, 13, 2, 1 << 15)
+    assert r["hits"] > 1000000 and min(r["blocks"]) > 300, r
+
+
+# ---- cfg3's tables with streaming, the step decided a frame ahead -------------------------------------------------
+
+EXT, DIMS, MINP, PARTS = (0.5, 0.5, 0.5), (65, 65, 65), (-32, -32, -32), 8
+STREAM_POS = np.array([0.0, 0.0, 1.6, 1.0], dtype=np.float32)
+RADIUS = 1.2
+
+
+def sorted_blocks(descs, blocks):
+    order = canonical.lexsort_pos(np.ascontiguousarray(descs["pos"]))
+    return np.ascontiguousarray(descs["pos"][order]), np.ascontiguousarray(blocks[order])
+
+
+@pytest.mark.slow
+def test_cfg3_native_loop_with_streaming_decided_ahead(E, oracle_lib, vh):
+    """BASELINE.json configs[2]: 1 cm voxels, 2 M buckets / 20 M entries, streaming on with the worker thread, through the
+    native loop with the streaming step decided a frame ahead (vh_stream_out_probe): frames with nothing to move take
+    three launches (alloc rides), frames with traffic take the reference's order of calls.  After every frame the table,
+    the voxels, the host chunk grid and the bit mask's population equal the oracle pair's (oracle/vh_oracle.c +
+    oracle/chunk_grid.py, single-threaded: streamOutToCPU, streamInToGPU, integrate), and every ray-cast map too."""
+    from oracle.chunk_grid import OracleChunkGrid
+    O = oracle_lib
+    c = dict(synth.CONFIGS["cfg3"])
+    c.update(num_sdf_blocks=1 << 14)
+    hp, cp, rp = synth.config_params(c)
+    hp.m_streamingVoxelExtents[:] = EXT
+    hp.m_streamingGridDimensions[:] = DIMS
+    hp.m_streamingMinGridPos[:] = MINP
+    rp = T.make_raycast_params(hp, cp)
+    n = 10
+    poses = [shifted_pose(k * 5) for k in range(n)]
+    frames = [E.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    host = [O.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    opt = T.make_scene_options(offline=False, gc=True, starve=4, streaming_out_parts=PARTS)
+    scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+    grid = E.CUDASceneRepChunkGrid(scene, EXT, DIMS, MINP, 2000, True, PARTS)  # worker thread running
+    ref = O.OracleScene(hp, cp, rp, opt)
+    og = OracleChunkGrid(ref, EXT, DIMS, MINP, PARTS)
+    recon = E.Reconstruction(scene, ray, grid, cp, E.Reconstruction.defaultOptions(
+        s_streamingEnabled=1, s_streamingPos=STREAM_POS[:3], s_streamingRadius=RADIUS, s_allocAhead=1, s_maxFramesInFlight=16))
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+    out = inn = 0
+    deterministic = True
+    shadow = O.OracleScene(hp, cp, rp, T.make_scene_options(offline=True, gc=True, starve=4, streaming_out_parts=PARTS))
+    sg = OracleChunkGrid(shadow, EXT, DIMS, MINP, PARTS)
+    for k in range(n):
+        # frame by frame; the loop is told the next frame's pose, so that it asks the device about that frame's streaming
+        # step behind this frame's alloc pass (vh_reconstruction_run_ahead), as it does inside a many-frame call
+        recon.run(seq, k, 1, lookahead=True)
+        recon.synchronize()
+        # the oracle pair, in the reference's order
+        if k > 0:
+            want = ref.render(poses[k - 1])
+        p = (poses[k].reshape(4, 4) @ STREAM_POS)[:3]
+        out += og.stream_out_to_cpu(p, RADIUS, True)
+        inn += og.stream_in_to_gpu(p, RADIUS, True)
+        ref.integrate(poses[k], host[k][0], host[k][1], og.bitmask)
+        sg.stream_out_to_cpu(p, RADIUS, True)
+        sg.stream_in_to_gpu(p, RADIUS, True)
+        shadow.integrate(poses[k], host[k][0], host[k][1], sg.bitmask)
+        deterministic = deterministic and np.array_equal(canonical.block_positions(ref.hash_table()), canonical.block_positions(shadow.hash_table()))
+        if k > 0:
+            assert_maps_equal(ray.download(), want, f"cfg3 streaming frame {k}: ray cast of pose {k - 1}")
+        canonical.assert_same_scene(scene.state(), ref.state(), f"cfg3 streaming frame {k}")
+        gd, gb = sorted_blocks(*grid.downloadHostBlocks())
+        od, ob = sorted_blocks(*og.host_blocks())
+        assert np.array_equal(gd, od), f"frame {k}: host chunk grid holds different blocks"
+        assert gb.tobytes() == ob.tobytes(), f"frame {k}: host voxel payloads differ"
+        assert grid.getStatistics()["bits"] == og.statistics()["bits"]
+        grid.debugCheckForDuplicates()
+    assert deterministic, "pick poses without same-pass bucket sharing"
+    st = recon.getStats()
+    assert st["frames"] == n
+    assert (st["blocksStreamedOut"], st["blocksStreamedIn"]) == (out, inn), (st, out, inn)
+    assert out > 50, "the sphere must be small enough for blocks to leave"
+    # both kinds of frame occurred: with the step known ahead to be a no-op (three launches), and with traffic
+    assert 1 <= st["streamingStepsSkipped"] < n, st
+    sw = scene.getState()
+    assert sw[T.STATE_HEAP_UNDERFLOW] == 0 and sw[T.STATE_INSERT_FAILED] == 0
+    recon.close()
+    grid.close()

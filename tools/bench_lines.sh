@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/${1:-r02aj}
+O=gpurun_out/${1:-bench_lines}
 mkdir -p $O
 timeout -k 10 500 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_20_5.json 2> $O/bench_driver_20_5.err; echo "bench 20/5 rc=$?"

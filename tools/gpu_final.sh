@@ -8,7 +8,7 @@ tail -3 gpurun_out/final_pytest_gpu.log
 [ $rc -ne 0 ] && exit 1
 timeout -k 10 300 python __graft_entry__.py smoke > gpurun_out/final_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/final_smoke.log
 bash tools/collect_profile.sh > gpurun_out/final_stdout.log 2>&1
-bash tools/gpu_s.sh final_lines
+bash tools/bench_lines.sh final_lines
 cp gpurun_out/final_lines/bench.json gpurun_out/final/bench.json
 cp gpurun_out/final_lines/bench_driver_20_5.json gpurun_out/final/bench_driver_20_5.json
 tail -3 gpurun_out/final_stdout.log

@@ -2,7 +2,7 @@
 # integrate-kernel iteration: the tests that cover it, then the kernel alone on the dense scene and the dense bench line
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/${1:-r02t}
+O=gpurun_out/${1:-integrate_iteration}
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_integrate_shapes.py tests/test_gpu_parity.py tests/test_gpu_frame_loop.py -m gpu -x -q --timeout 120 > $O/pytest.log 2>&1; rc=$?
 tail -5 $O/pytest.log

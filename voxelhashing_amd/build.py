@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvoxelhashing_amd.so")
-SOURCES = ["vh_kernels.hip", "vh_host.cpp", "vh_chunk_grid.cpp", "vh_marching_cubes.cpp", "vh_sensor.cpp", "vh_sensor_data.cpp", "vh_params.cpp", "vh_tracking.cpp", "vh_reconstruction.cpp", "vh_c_api.cpp"]
+SOURCES = ["vh_kernels.hip", "vh_probe.hip", "vh_host.cpp", "vh_chunk_grid.cpp", "vh_marching_cubes.cpp", "vh_sensor.cpp", "vh_sensor_data.cpp", "vh_params.cpp", "vh_tracking.cpp", "vh_reconstruction.cpp", "vh_c_api.cpp"]
 HEADERS = ["vh_device.hpp", "vh_host_util.hpp", "vh_stage_timer.hpp", "vh_handles.hpp",
            os.path.join(ROOT, "include", "vh_types.h"), os.path.join(ROOT, "include", "vh_api.h"),
            os.path.join(ROOT, "include", "vh.hpp"), os.path.join(ROOT, "include", "vh_mc_tables.h")]

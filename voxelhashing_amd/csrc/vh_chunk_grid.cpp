@@ -535,6 +535,19 @@ void CUDASceneRepChunkGrid::streamInFinish()
     hEventInProduce.set();
 }
 
+void CUDASceneRepChunkGrid::streamInAbort()
+{
+    if (!m_streamInLock.owns_lock()) return;
+    try {
+        // what the worker took out of the grid for this pass is still in its staging buffers (integrateInHash)
+        if (s_nStreamdInBlocks != 0) integrateInChunkGrid(h_SDFBlockDescInput, h_SDFBlockInput, s_nStreamdInBlocks);
+    } catch (...) {
+    }
+    s_nStreamdInBlocks = 0;
+    m_streamInLock.unlock();
+    hEventInProduce.set();
+}
+
 // DSC/CUDASceneRepChunkGrid.cpp:107-124
 void CUDASceneRepChunkGrid::streamOutToCPUPass1CPU(bool multiThreaded)
 {

@@ -38,6 +38,17 @@ inline void checkHip(hipError_t e, const char* what)
 // utility C ABI
 // ---------------------------------------------------------------------------
 
+namespace {
+thread_local hipEvent_t t_launchStart = nullptr, t_launchStop = nullptr;
+}
+bool vh_take_launch_events(hipEvent_t* start, hipEvent_t* stop)
+{
+    if (!t_launchStart || !t_launchStop) return false;
+    *start = t_launchStart; *stop = t_launchStop;
+    t_launchStart = t_launchStop = nullptr;
+    return true;
+}
+
 extern "C" {
 
 const char* vh_version(void) { return "voxelhashing_amd 0.1.0 (gfx950)"; }
@@ -52,6 +63,7 @@ const char* vh_error_string(int code)
     case VH_ERR_INSERT_FAILED: return "hash insert failed";
     case VH_ERR_BAD_ARGUMENT: return "bad argument";
     case VH_ERR_VERSION_MISMATCH: return "hashgrid version mismatch";
+    case VH_ERR_TIMEOUT: return "the device made no progress (time-out)";
     case VH_ERR_IO: return "file i/o error";
     default: return "unknown error";
     }
@@ -96,6 +108,13 @@ int vh_memcpy_d2h(void* dst, const void* src, size_t bytes, vhStream_t stream)
 int vh_memset(void* dst, int value, size_t bytes, vhStream_t stream)
 {
     VH_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return VH_OK;
+}
+int vh_time_next_launch(void* startEvent, void* stopEvent)
+{
+    if (!startEvent || !stopEvent) return VH_ERR_BAD_ARGUMENT;
+    t_launchStart = (hipEvent_t)startEvent;
+    t_launchStop = (hipEvent_t)stopEvent;
     return VH_OK;
 }
 int vh_stream_create(vhStream_t* out)
@@ -461,7 +480,7 @@ void CUDASceneRepHashSDF::integrateFused(const DepthCameraData& cam, const Depth
             flags |= VH_FUSED_STARVE;
     }
     const bool timed = m_options.s_timingsDetailledEnabled;
-    if (timed) m_timer->start(ST_INTEGRATE, (hipStream_t)m_stream);
+    if (timed) m_timer->arm(ST_INTEGRATE); // (the kernel's own dispatch time stamps)
     // the packed frame is this frame's only if this frame's alloc pass wrote it (same image, same size)
     const bool packedIsCurrent = m_job.allocLaunched && m_job.d_packedFrame && m_job.cam.d_depthData == cam.d_depthData &&
                                  m_job.cam.d_colorData == cam.d_colorData && m_job.cp.m_imageWidth == cp.m_imageWidth &&
@@ -469,7 +488,6 @@ void CUDASceneRepHashSDF::integrateFused(const DepthCameraData& cam, const Depth
     check(vh_integrate_fused(&m_hashData, &m_hashParams, &cam, &cp, flags, nextLockToken(), (uint32_t*)m_occupiedEvent,
                              m_numIntegratedFrames + 1u, packedIsCurrent ? m_job.d_packedFrame : nullptr, m_stream), "integrate (fused)");
     m_occupiedPending = true;
-    if (timed) m_timer->stop(ST_INTEGRATE, (hipStream_t)m_stream);
 }
 
 // first half of integrate(): the pose, and alloc + compactify as a job for a co-launch (see include/vh.hpp)
@@ -673,6 +691,7 @@ CUDARayCastSDF::CUDARayCastSDF(const RayCastParams& params, vhStream_t stream)
     check(vh_ray_interval_clear(d_tileHeads, params.m_width, params.m_height, m_stream), "vh_ray_interval_clear");
     d_schedule = nullptr;
     m_phase = 0;
+    m_preSplatsUsed = 0;
     std::memset(&m_preSplat, 0, sizeof(m_preSplat));
     const size_t schedBytes = vh_render_schedule_bytes(params.m_width, params.m_height);
     checkHip(hipMalloc((void**)&d_schedule, schedBytes), "render schedule");
@@ -744,6 +763,7 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     }
     m_preSplat.valid = false;
     if (preSplatted) {
+        m_preSplatsUsed++;
         m_phase = m_preSplat.phase;
         m_tileCapacity = m_preSplat.capacity;
     } else if (m_useIntervals) {
@@ -762,7 +782,8 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
         m_timer->start(ST_EMPTY, (hipStream_t)m_stream);
         m_timer->stop(ST_EMPTY, (hipStream_t)m_stream);
     }
-    if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream); // the march kernel alone
+    if (timed && m_useIntervals) m_timer->arm(ST_RAYCAST); // the march kernel alone, by its own dispatch time stamps
+    else if (timed) m_timer->start(ST_RAYCAST, (hipStream_t)m_stream);
     // Without gradients computeNormals rewrites every pixel of the normal map right after (MINF or a normal,
     // DSC/CameraUtil.cu:669-697), so the march does not write its MINF there first: a null map is skipped.
     RayCastData out = m_data;
@@ -774,9 +795,9 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
     } else {
         check(vh_render(&hashData, &hashParams, &out, &cp, &m_params, m_stream), "renderCS");
     }
-    if (timed) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
+    if (timed && !m_useIntervals) m_timer->stop(ST_RAYCAST, (hipStream_t)m_stream);
     if (!m_params.m_useGradients) {
-        if (timedAll) m_timer->start(ST_NORMALS, (hipStream_t)m_stream);
+        if (timedAll) m_timer->arm(ST_NORMALS);
         // With a job riding along, the NEXT render's splat rides too: that render's pose is the job's (the pose of
         // the frame being integrated), and the table it will see differs from the one listed here only by what the
         // frame's pass over the voxels frees and what the next alloc adds (vh_compute_normals_co2).
@@ -802,6 +823,5 @@ void CUDARayCastSDF::render(const HashData& hashData, const HashParams& hashPara
         } else {
             check(vh_compute_normals_co(m_data.d_normals, m_data.d_depth4, m_params.m_width, m_params.m_height, coLaunch, m_stream), "computeNormals");
         }
-        if (timedAll) m_timer->stop(ST_NORMALS, (hipStream_t)m_stream);
     }
 }

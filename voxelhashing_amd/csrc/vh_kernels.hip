@@ -205,8 +205,8 @@ __global__ __launch_bounds__(512) void k_alloc(VhHashData hd, VhHashParams hp, V
 //
 // The reference scans all Ne entries (32 B each) every frame.  Here the
 // 1-bit-per-bucket summary is scanned instead (Nb/8 bytes) and only non-empty
-// buckets are opened; kept entries are packed with wave64 ballot + popcount
-// prefix and ONE atomic per wave.
+// buckets are opened; kept entries queue up in LDS and the workgroup appends
+// them to the list with ONE atomic (compactify_group below).
 // ---------------------------------------------------------------------------
 
 // v_cvt_i32_f32 truncates, saturates and sends NaN to 0 by itself: f2i() without the v_trunc_f32 the compiler puts in front
@@ -529,7 +529,8 @@ VHD Vox integrate_voxel_packed(const VhHashParams& hp, const VhDepthCameraParams
 //   * few blocks (count <= workgroups): one WORKGROUP per block, two x-adjacent voxels (16 B) per lane -- the frame is
 //     a latency chain (entry -> voxels -> gather -> table edit), and four waves per block keep it short;
 //   * many blocks: one WAVE per block (4 KB = four 16-byte loads per lane), at most 5120 waves (five per SIMD; the
-//     active waves fill whole workgroups) that draw further blocks off a ticket counter.  min |sdf| / max weight are a
+//     active waves fill whole workgroups); wave w takes blocks w, w + 5120, ... -- dealt statically (a ticket counter
+//     was measured: 165 us, agent-scope atomics on one address are served one after the other).  min |sdf| / max weight are a
 //     wave reduction (no LDS, no barrier); lane 0 edits the table; the block's screen footprint is staged in LDS and
 //     blocks whose corners pass a range certificate take the packed arithmetic of integrate_block_certified (below).
 // Load j of lane l of a wave that holds a whole block: voxels 128 j + 2 l and + 1, i.e. x = 2l mod 8 (+1),
@@ -3422,8 +3423,8 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
     args.hd = *hd; args.hp = *hp; args.cam = *cam; args.cp = *cp;
     args.flags = flags; args.lockToken = lockToken; args.countMirror = d_countMirror; args.mirrorTag = mirrorTag;
     args.packed = reinterpret_cast<const uint2*>(packed);
-    if (packed) k_integrate_fused<true><<<grid, 256, 0, (hipStream_t)stream>>>(args);
-    else k_integrate_fused<false><<<grid, 256, 0, (hipStream_t)stream>>>(args);
+    if (packed) VH_LAUNCH_TIMED(k_integrate_fused<true>, grid, 256, (hipStream_t)stream, args);
+    else VH_LAUNCH_TIMED(k_integrate_fused<false>, grid, 256, (hipStream_t)stream, args);
     return vh_last_launch_error();
 }
 
@@ -3519,11 +3520,11 @@ int vh_render_intervals_co(const VhHashData* hd, const VhHashParams* hp, const V
     const dim3 grid(groups);
     hipStream_t st = (hipStream_t)stream;
     if (rp->m_useGradients) {
-        if (large) k_render_large<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
-        else k_render<true><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
+        if (large) VH_LAUNCH_TIMED(k_render_large<true>, grid, 256, st, *hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
+        else VH_LAUNCH_TIMED(k_render<true>, grid, 256, st, *hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
     } else {
-        if (large) k_render_large<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
-        else k_render<false><<<grid, 256, 0, st>>>(*hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
+        if (large) VH_LAUNCH_TIMED(k_render_large<false>, grid, 256, st, *hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
+        else VH_LAUNCH_TIMED(k_render<false>, grid, 256, st, *hd, *hp, *rd, *cp, *rp, h, l, cap, d_schedule, phase, job);
     }
     return vh_last_launch_error();
 }
@@ -3589,7 +3590,7 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
             groups += sp.groups;
         }
     }
-    k_compute_normals<<<groups, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job, sp);
+    VH_LAUNCH_TIMED(k_compute_normals, groups, 256, (hipStream_t)stream, reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job, sp);
     return vh_last_launch_error();
 }
 

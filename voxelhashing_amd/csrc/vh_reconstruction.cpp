@@ -7,12 +7,17 @@
 //   [stream out around the camera; stream in]                  :881-900
 //   integrate(pose, depth, colour, bit mask)                   :903
 // What is not in the reference:
-//   * s_allocAhead: the pose of frame k is known before pose k-1 is ray-cast (it comes from the file), so alloc +
-//     compactify of frame k are enqueued first, on the scene's side stream, and run beside the ray cast;
+//   * s_allocAhead: the pose of frame k is known before pose k-1 is ray-cast (it comes from the file), so the frame's
+//     alloc pass rides in the ray caster's launch (its last workgroups) and its compactify pass, with the next pose's
+//     interval splat, in computeNormals' (CUDASceneRepHashSDF::integrateAhead hands out the job): three launches per
+//     frame on ONE stream, no event.  With streaming on this happens in the frames whose streaming step is known a
+//     frame ahead to be a no-op (vh_stream_out_probe; frame() below);
 //   * s_framesOnHost: float depth + RGBX colour in host memory (what RGBDSensor::getDepthFloat / getColorRGBX hand
-//     to CUDARGBDAdapter::process, DSC/CUDARGBDAdapter.cpp:107-131) are uploaded on a copy stream into one of two
-//     staging slots, beside the previous frame's work, and the colour is converted there (convertColorRawToFloat4);
-//   * s_maxFramesInFlight: the host stays at most that many frames ahead of the device.
+//     to CUDARGBDAdapter::process, DSC/CUDARGBDAdapter.cpp:107-131) are uploaded by two copy streams (one copy engine
+//     each: depth, colour) into a ring of kStagingSlots = 4 staging slots, beside the previous frames' work, and the
+//     colour is converted there (convertColorRawToFloat4);
+//   * s_maxFramesInFlight: the host stays at most that many frames ahead of the device (polled through the mapped
+//     frame counter the fused integrate pass writes: no event).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -74,6 +79,7 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
                                const DepthCameraParams& cp, const ReconstructionOptions& options)
     : m_sceneRep(sceneRep), m_rayCast(rayCast), m_chunkGrid(chunkGrid), m_cp(cp), m_opt(options), m_frameNumber(0), m_copyStream(nullptr), m_copyStream2(nullptr)
 {
+    m_debugFailRender = 0;
     if (!sceneRep) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: no scene");
     if (options.s_streamingEnabled && !chunkGrid) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: streaming needs a chunk grid");
     if (options.s_renderEnabled && !rayCast) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: rendering needs a ray caster");
@@ -186,7 +192,7 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
             }
             std::this_thread::yield();
             waited = true;
-            if (now() - w0 > 30.0) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: the device made no progress for 30 s");
+            if (now() - w0 > 30.0) throw vh::Error(VH_ERR_TIMEOUT, "Reconstruction: the device made no progress for 30 s");
         }
         if (waited) m_stats.hostWaitSeconds += now() - w0;
     }
@@ -225,6 +231,9 @@ DepthCameraData Reconstruction::upload(const SequenceFrame& f)
         }
     }
     if (timed) {
+        // the pair spans the whole upload: the depth copy runs on the other stream, so this one waits for it first
+        // (t0 was recorded before either copy was enqueued; both streams were idle or busy with earlier uploads)
+        if (!mapped) checkHip(hipStreamWaitEvent(cs, (hipEvent_t)m_slotReady2[slot], 0), "hipStreamWaitEvent");
         checkHip(hipEventRecord((hipEvent_t)t1, cs), "hipEventRecord");
         m_uploadTimers.emplace_back(t0, t1);
     }
@@ -275,13 +284,29 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     // an unchanged bit mask the step is a no-op, and the frame runs as it does without streaming: three launches.
     enum Step { kFull, kAfterOut, kNothing } step = kFull;
     unsigned int nIn = 0;
+    // Two hand-offs of this function are in two halves with other calls in between (the ray cast, which may throw):
+    // streamInWait() ... streamInFinish() holds the worker's mutex and owes it an event -- a later stopMultiThreading(),
+    // reset() or destruction of the grid would wait for that worker forever -- and integrateAhead() ... integrateFinish()
+    // leaves the scene refusing every integrate() until it is finished.  On unwind both are put back.
+    struct Unwind {
+        CUDASceneRepChunkGrid* grid;
+        CUDASceneRepHashSDF* scene;
+        bool streamIn = false, ahead = false;
+        ~Unwind()
+        {
+            if (streamIn) { try { grid->streamInAbort(); } catch (...) {} }
+            if (ahead) scene->abortAhead();
+        }
+    } unwind{ m_chunkGrid, m_sceneRep };
     if (threaded && m_probePending && std::memcmp(m_probePose, f.rigidTransform, sizeof(m_probePose)) == 0) {
         const double t0 = now();
         if (m_chunkGrid->probeResult() == 0) {
             m_chunkGrid->streamOutNothing(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts);
             nIn = m_chunkGrid->streamInWait();
+            unwind.streamIn = true;
             step = (nIn == 0 && !m_chunkGrid->bitMaskDirty()) ? kNothing : kAfterOut;
             if (step == kNothing) {
+                unwind.streamIn = false; // (streamInFinish() cleans up after itself)
                 m_chunkGrid->streamInFinish(); // (launches nothing; hands the buffers back to the worker)
                 m_stats.streamingStepsSkipped++;
             }
@@ -296,14 +321,23 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     // :750-751 (the pose the scene holds is the previous frame's)
     const vh::mat4f renderTransform = m_sceneRep->getLastRigidTransform();
     VhFrameJob* job = nullptr;
-    if (ahead) job = m_sceneRep->integrateAhead(transformation, cam, m_cp, d_bitMask);
-    if (m_frameNumber > 0 && m_opt.s_renderEnabled) // :750 "getFrameNumber() > 1" with frames counted from 1
+    if (ahead) {
+        job = m_sceneRep->integrateAhead(transformation, cam, m_cp, d_bitMask);
+        unwind.ahead = true;
+    }
+    if (m_frameNumber > 0 && m_opt.s_renderEnabled) {
+        if (m_debugFailRender && --m_debugFailRender == 0) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: injected failure of the ray cast (vh_reconstruction_debug_fail_render)"); // :750 "getFrameNumber() > 1" with frames counted from 1
+        const unsigned int used0 = m_rayCast->getNumSplatsMadeAheadUsed();
         m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform, job); // :763
+        m_stats.splatsMadeAheadUsed += m_rayCast->getNumSplatsMadeAheadUsed() - used0;
+        if (job && job->allocLaunched && job->compactifyLaunched) m_stats.framesWithRiders++;
+    }
 
     if (streaming && step != kNothing) { // :881-900
         const double t0 = now();
         unsigned int nStreamedBlocks = 0;
         if (step == kAfterOut) {
+            unwind.streamIn = false;
             m_chunkGrid->streamInFinish();
             m_stats.blocksStreamedIn += nIn;
         } else if (m_opt.s_offlineProcessing) {
@@ -342,6 +376,7 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     if (ask && allocIsIn) askNow();
 
     if (m_opt.s_integrationEnabled) { // :903
+        unwind.ahead = false; // (integrateFinish() closes the job first thing)
         if (ahead) m_sceneRep->integrateFinish(cam, m_cp);
         else m_sceneRep->integrate(transformation, cam, m_cp, d_bitMask);
     } else {
@@ -352,7 +387,7 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     m_stats.frames++;
 }
 
-void Reconstruction::run(const SequenceFrame* frames, unsigned int n)
+void Reconstruction::run(const SequenceFrame* frames, unsigned int n, const SequenceFrame* after)
 {
     if (n && !frames) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction::run: null frames");
     const double t0 = now();
@@ -367,11 +402,11 @@ void Reconstruction::run(const SequenceFrame* frames, unsigned int n)
             const double w0 = now();
             while (m_sceneRep->getNumIntegratedFrames() - m_sceneRep->getNumFramesStartedOnDevice() >= m_opt.s_maxFramesInFlight) {
                 std::this_thread::yield();
-                if (now() - w0 > 30.0) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction::run: the device made no progress for 30 s");
+                if (now() - w0 > 30.0) throw vh::Error(VH_ERR_TIMEOUT, "Reconstruction::run: the device made no progress for 30 s");
             }
             waited += now() - w0;
         }
-        frame(frames[i], i + 1 < n ? &frames[i + 1] : nullptr);
+        frame(frames[i], i + 1 < n ? &frames[i + 1] : after);
     }
     const double total = now() - t0, streamWait = m_stats.hostWaitSeconds - streamWait0;
     m_stats.hostWaitSeconds += waited;
@@ -409,10 +444,20 @@ int vh_reconstruction_run(VhReconstruction* r, const VhSequenceFrame* frames, ui
     if (!r || (n && !frames)) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { r->impl.run(frames, n); });
 }
+int vh_reconstruction_run_ahead(VhReconstruction* r, const VhSequenceFrame* frames, uint32_t n, const VhSequenceFrame* next)
+{
+    if (!r || (n && !frames)) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.run(frames, n, next); });
+}
 int vh_reconstruction_synchronize(VhReconstruction* r)
 {
     if (!r) return VH_ERR_BAD_ARGUMENT;
     return guarded([&] { r->impl.synchronize(); });
+}
+int vh_reconstruction_debug_fail_render(VhReconstruction* r, uint32_t nthRenderFromNow)
+{
+    if (!r) return VH_ERR_BAD_ARGUMENT;
+    return guarded([&] { r->impl.debugFailRender(nthRenderFromNow); });
 }
 int vh_reconstruction_get_stats(VhReconstruction* r, VhReconstructionStats* out)
 {

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/vh_api.h"
+
 #include <cstdint>
 #include <utility>
 #include <vector>
@@ -43,6 +45,14 @@ struct VhStageTimer {
         (void)hipEventRecord(e, s);
         pending[stage].push_back(std::make_pair(open[stage], e));
         open[stage] = nullptr;
+    }
+    // the NEXT kernel this thread launches (one of those that go through VH_LAUNCH_TIMED: the ray caster, computeNormals,
+    // the fused integrate pass) is timed by its own dispatch time stamps: no record before or behind it
+    void arm(int stage)
+    {
+        hipEvent_t a = get(), b = get();
+        (void)vh_time_next_launch((void*)a, (void*)b);
+        pending[stage].push_back(std::make_pair(a, b));
     }
     // waits for the stream and folds all finished pairs into the totals
     void resolve(hipStream_t s)

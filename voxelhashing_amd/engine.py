@@ -398,19 +398,27 @@ class Reconstruction:
         except Exception:
             pass
 
-    def run(self, frames, first=0, count=None):
-        """frames: a VhSequenceFrame array (makeFrames); processes frames[first:first+count]"""
+    def run(self, frames, first=0, count=None, lookahead=False):
+        """frames: a VhSequenceFrame array (makeFrames); processes frames[first:first+count].  lookahead: the loop may
+        read the pose of frames[first+count], the frame a later call will bring (vh_reconstruction_run_ahead)"""
         n = len(frames) - first if count is None else count
         if n <= 0:
             return
         ptr = C.cast(C.byref(frames, first * C.sizeof(T.SequenceFrame)), C.POINTER(T.SequenceFrame))
-        check(self.L.vh_reconstruction_run(self.handle, ptr, n), "Reconstruction::run")
+        if lookahead and first + n < len(frames):
+            nxt = C.cast(C.byref(frames, (first + n) * C.sizeof(T.SequenceFrame)), C.POINTER(T.SequenceFrame))
+            check(self.L.vh_reconstruction_run_ahead(self.handle, ptr, n, nxt), "Reconstruction::run")
+        else:
+            check(self.L.vh_reconstruction_run(self.handle, ptr, n), "Reconstruction::run")
 
     def synchronize(self):
         check(self.L.vh_reconstruction_synchronize(self.handle), "Reconstruction::synchronize")
 
     def reset(self):
         check(self.L.vh_reconstruction_reset(self.handle), "Reconstruction::reset")
+
+    def debugFailRender(self, nth_render_from_now):
+        check(self.L.vh_reconstruction_debug_fail_render(self.handle, int(nth_render_from_now)), "Reconstruction::debugFailRender")
 
     def getStats(self):
         st = T.ReconstructionStats()

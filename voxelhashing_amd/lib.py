@@ -31,6 +31,7 @@ PROTOTYPES = {
     "vh_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "vh_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "vh_memset": (C.c_int, [_VP, C.c_int, C.c_size_t, _VP]),
+    "vh_time_next_launch": (C.c_int, [_VP, _VP]),
     "vh_stream_create": (C.c_int, [P(_VP)]),
     "vh_stream_destroy": (C.c_int, [_VP]),
     "vh_stream_synchronize": (C.c_int, [_VP]),
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "vh_synth_frame": (C.c_int, [_VP, C.c_int, C.c_int, _F16, P(T.DepthCameraParams), _VP, _VP, _VP]),
     "vh_debug_hash_ops": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
     "vh_debug_check_fast_math": (C.c_int, [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _VP, _VP]),
+    "vh_debug_valu_probe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _VP, P(C.c_uint32), _VP]),
     "vh_debug_check_refined_division": (C.c_int, [C.c_uint32, C.c_uint32, _VP, _VP]),
     "vh_publish_words": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP]),
     "vh_stream_out_probe": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_float, _VP, _VP, _VP, C.c_uint32, _VP]),
@@ -100,7 +102,9 @@ PROTOTYPES = {
     "vh_reconstruction_create": (C.c_int, [_VP, _VP, _VP, P(T.DepthCameraParams), P(T.ReconstructionOptions), P(_VP)]),
     "vh_reconstruction_destroy": (None, [_VP]),
     "vh_reconstruction_run": (C.c_int, [_VP, P(T.SequenceFrame), C.c_uint32]),
+    "vh_reconstruction_run_ahead": (C.c_int, [_VP, P(T.SequenceFrame), C.c_uint32, P(T.SequenceFrame)]),
     "vh_reconstruction_synchronize": (C.c_int, [_VP]),
+    "vh_reconstruction_debug_fail_render": (C.c_int, [_VP, C.c_uint32]),
     "vh_reconstruction_get_stats": (C.c_int, [_VP, P(T.ReconstructionStats)]),
     "vh_reconstruction_reset": (C.c_int, [_VP]),
     "vh_convert_color_raw_to_float4": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),

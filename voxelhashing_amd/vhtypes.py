@@ -256,6 +256,8 @@ class ReconstructionStats(C.Structure):
         ("streamingStepsSkipped", C.c_uint64),
         ("heapUnderflows", C.c_uint64),
         ("failedInserts", C.c_uint64),
+        ("framesWithRiders", C.c_uint64),
+        ("splatsMadeAheadUsed", C.c_uint64),
     ]
 
 
