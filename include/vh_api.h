@@ -230,7 +230,7 @@ int vh_debug_check_fast_math(float divisor, uint32_t modulus, uint32_t n, uint32
 int vh_debug_check_refined_division(uint32_t n, uint32_t seed, uint32_t* d_mismatches, vhStream_t stream);
 /* measurement, not part of the path: every SIMD of the device runs `wavesPerSimd` waves (1..8), each a chain-free stream of
  * 32 * iters vector instructions (mode 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_add_u32, 3 v_mul_lo_u32); per wave
- * {start, end in 100 MHz ticks, s_memtime ticks spent, hardware id} into d_stamps (4 words per wave, *numWaves waves: room for
+ * {start, end in 100 MHz ticks, s_memtime ticks spent, HW_ID[19:0] | XCC_ID << 20} into d_stamps (4 words per wave, *numWaves waves: room for
  * 8 * 4 * the device's compute units).  tools/valu_issue_probe.py turns that into cycles per wave-instruction per SIMD */
 int vh_debug_valu_probe(uint32_t mode, uint32_t wavesPerSimd, uint32_t iters, uint32_t* d_stamps, uint32_t* numWaves, vhStream_t stream);
 

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void k_valu_probe(uint32_t iters, uint4* stamp
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
     if (lane == 0u) {
         const uint32_t w = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u;
-        // {start, end in 100 MHz ticks, s_memtime ticks spent, hardware id}
-        stamps[w] = make_uint4((uint32_t)r0, (uint32_t)r1, (uint32_t)(c1 - c0), __builtin_amdgcn_s_getreg((31 << 11) | 4));
+        // {start, end in 100 MHz ticks, s_memtime ticks spent, where: HW_ID[19:0] (wave, SIMD, pipe, CU, SH, SE, TG) | XCC_ID << 20}
+        const uint32_t hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        stamps[w] = make_uint4((uint32_t)r0, (uint32_t)r1, (uint32_t)(c1 - c0), (hwid & 0xfffffu) | ((xcc & 0xfu) << 20));
     }
     if (out == 123.456f) *sink = out; // keeps the chains alive
 }
