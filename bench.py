@@ -713,7 +713,8 @@ def main(argv=None):
         if wl.streaming:
             result["streaming"] = dict(sphere_centre_z=wl.streaming_sphere[0], sphere_radius=wl.streaming_sphere[1], chunk_extent=wl.streaming_sphere[2],
                                        parts=int(wl.opt.s_streamingOutParts), worker_thread=True,
-                                       frames_without_a_streaming_step=int(st1.get("streamingStepsSkipped", 0) - st0.get("streamingStepsSkipped", 0)), blocks_out=int(st1["blocksStreamedOut"] - st0["blocksStreamedOut"]),
+                                       frames_without_a_streaming_step=int(st1.get("streamingStepsSkipped", 0) - st0.get("streamingStepsSkipped", 0)),
+                                       frames_pipelined=int(st1.get("streamingFramesPipelined", 0) - st0.get("streamingFramesPipelined", 0)), blocks_out=int(st1["blocksStreamedOut"] - st0["blocksStreamedOut"]),
                                        blocks_in=int(st1["blocksStreamedIn"] - st0["blocksStreamedIn"]),
                                        blocks_per_second=round((st1["blocksStreamedOut"] - st0["blocksStreamedOut"] + st1["blocksStreamedIn"] - st0["blocksStreamedIn"]) / elapsed, 1))
     wl.close()

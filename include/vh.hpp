@@ -283,6 +283,47 @@ public:
     void streamInAbort();
     bool bitMaskDirty() const { return m_bitMaskDirty; }
     unsigned int integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts);
+
+    // ---- the streaming step of a frame without a host wait (not in the reference; used by Reconstruction for a sequence
+    // whose poses are known a frame ahead).  The reference's step is a chain of four host <-> device round trips: the
+    // stream-out count is read back before the blocks are copied, the host puts the blocks into its grid and only then knows
+    // the bit mask the frame's alloc pass needs, the worker picks the chunk that comes in, the heap counter is read back
+    // before it is inserted.  Here
+    //   * the counts stay on the device (vh_stream_out_device / vh_stream_in_device), and the stream-out pass writes the
+    //     blocks straight into mapped host memory;
+    //   * the DEVICE's copy of the bit mask is kept by the passes themselves (a block that leaves sets its chunk's bit, a
+    //     chunk that comes in clears it): what the frame's alloc pass reads is in place without the host;
+    //   * the chunk that comes in at frame k+1 is chosen and uploaded by a worker thread while the device is still working
+    //     on frame k.  It may be chosen that early: a chunk gains blocks at frame k+1 only from blocks OUTSIDE that frame's
+    //     sphere, and a chunk with such a block does not lie entirely inside the sphere, so what leaves in a frame cannot
+    //     be what comes in in the same frame (isChunkInSphere is the conservative test of the chunk's bounding sphere);
+    //   * the blocks that left at frame k are put into the host grid by that worker when their copy has arrived, before it
+    //     chooses for frame k+1 -- the one order the choice does depend on.
+    // Per frame: pipelineDecision() (the worker's answer for this frame) -> [the ray cast] -> pipelineStreamOut() ->
+    // pipelineStreamIn() -> [integrate with getBitMaskDevice()] -> pipelineAsk() (the job for the next frame).
+    // Every other entry point of this class drains the pipeline first (pipelineDrain()).
+    struct StreamDecision {
+        unsigned int nIn;      // blocks of the chunk that comes in (0: none)
+        unsigned int chunkBit; // its bit in the bit mask
+        int slot;              // which staging buffer holds them
+    };
+    bool pipelineHasDecision(const vh::vec3f& posCamera, float radius) const; // was pipelineAsk() called for this frame's sphere?
+    StreamDecision pipelineDecision();  // waits for the worker (it has had most of a frame)
+    // enqueues the frame's stream-out pass for at most `mostBlocks` blocks (vh_stream_out_probe's count; 0: nothing is
+    // launched) and advances the part counter; false if mostBlocks exceeds the pipeline's staging (the caller then takes the
+    // reference's order of calls: pipelineDrain() and the classic methods)
+    bool pipelineStreamOut(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int mostBlocks);
+    void pipelineStreamIn(const StreamDecision& d); // enqueues the insert of what the worker has uploaded
+    // the job for the worker: take in what this frame's stream-out pass copies, then (haveNext) choose for the next frame
+    void pipelineAsk(bool haveNext, const vh::vec3f& nextPosCamera, float nextRadius);
+    // waits for the worker's job and looks at the outcome of finished inserts (repairs failures).  undo: a choice that has
+    // been made for a coming frame is put back into the grid (whoever looks at the host grid or takes the reference's order
+    // of calls next must find it as the reference would have it at this point; the next frame then chooses again)
+    void pipelineDrain(bool undo = true);
+    void pipelineReturn(const StreamDecision& d, const vh::vec3f& posCamera, float radius); // hands an unused pipelineDecision() back
+    unsigned int pipelineCapacity() const { return (unsigned int)kPipelineBlocks; }
+    unsigned int* getBitMaskDevice() { return d_bitMask; } // (current while the pipeline runs: no upload)
+    void pipelineTotals(unsigned long long* blocksOut, unsigned long long* blocksIn); // drains; blocks moved by the pipeline so far
     // blocks that stream-in passes could not insert and that went back to the host grid (not in the reference)
     unsigned int getNumFailedInserts() const { return m_numFailedInserts; }
 
@@ -345,6 +386,52 @@ private:
     void setBit(unsigned int index);
     void resetBit(unsigned int index);
     void takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev);
+    void takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev, const SDFBlockDesc* descs, const vh::SDFBlock* blocks, unsigned int& nIn);
+    unsigned int integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts, SDFBlockDesc* hDescs, vh::SDFBlock* hBlocks,
+                                 SDFBlockDesc* dDescs, vh::SDFBlock* dBlocks, unsigned int capacity, unsigned int* chunkBit);
+    // the pipeline (see above)
+    enum { kPipelineBlocks = 4096 }; // staging capacity of a pipelined pass (16 MB per buffer)
+    struct PipelineJob {
+        bool haveOut, haveNext;
+        uint32_t outTag, outMost;
+        int outSlot, inSlot;
+        vh::vec3f nextPos;
+        float nextRadius;
+    };
+    void pipelineStart();
+    void pipelineStop();
+    void pipelineWorker();
+    void pipelineCheckInsert(int slot, bool block);
+    std::thread m_plThread;
+    std::mutex m_plMutex;
+    std::condition_variable m_plCv;
+    bool m_plStarted, m_plQuit;
+    PipelineJob m_plJob;
+    std::atomic<unsigned int> m_plPosted, m_plDone; // jobs handed to / finished by the worker
+    std::atomic<int> m_plError;                     // a vh error code the worker ran into (reported by the next call)
+    StreamDecision m_plDecision;                    // the finished job's choice
+    bool m_plDecisionValid;                         // ... if it was asked for
+    vh::vec3f m_plDecisionPos;                      // ... and the sphere it was asked for
+    float m_plDecisionRadius;
+    unsigned int m_plFrame;                         // frames the pipeline has run (slot = frame & 1)
+    bool m_plOutThisFrame;                          // pipelineStreamOut() of the current frame launched a pass
+    uint32_t m_plOutTag, m_plOutMost;
+    struct { bool pending; uint32_t tag; unsigned int nIn; } m_plInsert[2]; // per staging slot: an insert whose outcome has not been looked at
+    std::atomic<unsigned long long> m_plBlocksOut, m_plBlocksIn;
+    SDFBlockDesc* d_plOutDesc[2];      // pass 1 -> pass 2 (device)
+    SDFBlockDesc* h_plOutDesc[2];      // mapped pinned: pass 2 writes the blocks it moves straight to the host
+    vh::SDFBlock* h_plOutBlocks[2];
+    SDFBlockDesc* hd_plOutDesc[2];     // their device aliases
+    vh::SDFBlock* hd_plOutBlocks[2];
+    uint32_t* h_plOutMirror[2];        // mapped pinned {count, 0, tag}
+    uint32_t* hd_plOutMirror[2];
+    SDFBlockDesc* h_plInDesc[2];       // pinned staging of the worker's upload
+    vh::SDFBlock* h_plInBlocks[2];
+    SDFBlockDesc* d_plInDesc[2];
+    vh::SDFBlock* d_plInBlocks[2];
+    uint32_t* h_plInMirror[2];         // mapped pinned {failed, heap counter before, tag, exhausted}, per staging slot
+    uint32_t* hd_plInMirror[2];
+    uint32_t m_plTag;
     void streamInLaunches();
     unsigned int m_numFailedInserts;
 
@@ -429,6 +516,7 @@ public:
 
 private:
     unsigned int m_debugFailRender;
+    unsigned long long m_pipelineOutSeen, m_pipelineInSeen; // the grid's pipeline totals already in m_stats
     void frame(const SequenceFrame& f, const SequenceFrame* next);
     bool m_probePending;        // a stream-out probe for the frame with pose m_probePose is in the stream
     float m_probePose[16];

@@ -192,6 +192,24 @@ int vh_stream_out_probe(const VhHashData* hd, const VhHashParams* hp, uint32_t t
 /* integrateFromGlobalHashPass2CUDA(params, hashData, threadsPerPart, descs, d_output, n)  :115 */
 int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSDFBlockDesc* d_descs,
                         VhVoxel* d_output, uint32_t nSDFBlocks, vhStream_t stream);
+/* ---- the streaming passes for a caller that does not wait for the device (not in the reference: its host reads a counter back
+ * before every second launch, DSC/CUDASceneRepChunkGrid.cu:88,140).
+ * vh_stream_out_device: integrateFromGlobalHashPass1CUDA + Pass2CUDA in one call.  The counter is cleared, pass 1 lists at most
+ * `mostBlocks` blocks (an upper bound the caller has from vh_stream_out_probe) and sets, in d_bitMask (may be NULL), the bit of
+ * every listed block's chunk -- what the host's integrateInChunkGrid does when the block arrives; pass 2 is launched for
+ * mostBlocks blocks and reads the count on the device.
+ * vh_publish_count: {*d_counter, 0, tag} into mapped host memory (tag last, system scope), to be enqueued behind the copies of
+ * the pass's output.
+ * vh_stream_in_device: chunkToGlobalHashPass1CUDA + Pass2CUDA + the heap counter's update with the counter read on the device;
+ * clears bit `chunkBit` of d_bitMask (0xffffffff: none); publishes {blocks that found no slot (listed in d_failed[1..]), heap
+ * counter before the pass, tag, 1 if the heap held too few free blocks -- then nothing was inserted} to d_mapped. */
+int vh_stream_out_device(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start, float radius,
+                         const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_descs, VhVoxel* d_blocks,
+                         uint32_t mostBlocks, int32_t lockToken, uint32_t* d_bitMask, vhStream_t stream);
+int vh_publish_count(const uint32_t* d_counter, uint32_t* d_mapped, uint32_t tag, vhStream_t stream);
+int vh_stream_in_device(const VhHashData* hd, const VhHashParams* hp, uint32_t n, const VhSDFBlockDesc* d_descs, const VhVoxel* d_blocks,
+                        int32_t lockToken, uint32_t* d_failed, uint32_t* d_bitMask, uint32_t chunkBit, uint32_t* d_mapped, uint32_t tag,
+                        vhStream_t stream);
 /* chunkToGlobalHashPass1CUDA(params, hashData, n, heapCountPrev, descs, blocks)           :162 */
 int vh_stream_in_pass1(const VhHashData* hd, const VhHashParams* hp, uint32_t n, uint32_t heapCountPrev,
                        const VhSDFBlockDesc* d_descs, int32_t lockToken, vhStream_t stream);

@@ -267,12 +267,14 @@ typedef struct VhReconstructionStats {
                                     spans both copy streams) */
     uint64_t uploadsTimed;
     uint64_t uploadBytes;        /* bytes per frame upload */
-    uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to be a no-op and ran with three launches */
+    uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to move nothing and that ran with three launches */
     uint64_t heapUnderflows;     /* the scene's status words as get_stats() found them (VH_STATE_*): alloc requests that found */
     uint64_t failedInserts;      /* the voxel pool empty; stream-in inserts that found no slot (the blocks went back to the host grid) */
     uint64_t framesWithRiders;   /* frames whose alloc pass rode in the ray caster's launch and whose compactify pass rode in computeNormals' */
     uint64_t splatsMadeAheadUsed; /* ray casts that ran on an interval splat made ahead (inside the previous computeNormals launch): such a
                                      frame is three launches -- k_render, k_compute_normals, k_integrate_fused */
+    uint64_t streamingFramesPipelined; /* frames whose streaming step ran without a host wait (CUDASceneRepChunkGrid's pipeline: counts on the
+                                          device, the chunk that comes in chosen a frame ahead); streamingStepsSkipped of them moved nothing */
 } VhReconstructionStats;
 
 /* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt

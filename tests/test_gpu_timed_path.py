@@ -145,10 +145,11 @@ def sorted_blocks(descs, blocks):
 @pytest.mark.slow
 def test_cfg3_native_loop_with_streaming_decided_ahead(E, oracle_lib, vh):
     """BASELINE.json configs[2]: 1 cm voxels, 2 M buckets / 20 M entries, streaming on with the worker thread, through the
-    native loop with the streaming step decided a frame ahead (vh_stream_out_probe): frames with nothing to move take
-    three launches (alloc rides), frames with traffic take the reference's order of calls.  After every frame the table,
+    native loop with the streaming step pipelined (CUDASceneRepChunkGrid's pipeline: counts on the device, the device's own
+    bit mask, the chunk that comes in chosen a frame ahead by the worker): frames with nothing to move take three launches
+    (alloc rides), frames with traffic the reference's order of launches without a host wait.  After every call the table,
     the voxels, the host chunk grid and the bit mask's population equal the oracle pair's (oracle/vh_oracle.c +
-    oracle/chunk_grid.py, single-threaded: streamOutToCPU, streamInToGPU, integrate), and every ray-cast map too."""
+    oracle/chunk_grid.py, single-threaded: streamOutToCPU, streamInToGPU, integrate), and the ray-cast maps too."""
     from oracle.chunk_grid import OracleChunkGrid
     O = oracle_lib
     c = dict(synth.CONFIGS["cfg3"])
@@ -158,7 +159,7 @@ def test_cfg3_native_loop_with_streaming_decided_ahead(E, oracle_lib, vh):
     hp.m_streamingGridDimensions[:] = DIMS
     hp.m_streamingMinGridPos[:] = MINP
     rp = T.make_raycast_params(hp, cp)
-    n = 10
+    n = 12
     poses = [shifted_pose(k * 5) for k in range(n)]
     frames = [E.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
     host = [O.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
@@ -174,24 +175,28 @@ def test_cfg3_native_loop_with_streaming_decided_ahead(E, oracle_lib, vh):
     deterministic = True
     shadow = O.OracleScene(hp, cp, rp, T.make_scene_options(offline=True, gc=True, starve=4, streaming_out_parts=PARTS))
     sg = OracleChunkGrid(shadow, EXT, DIMS, MINP, PARTS)
-    for k in range(n):
-        # frame by frame; the loop is told the next frame's pose, so that it asks the device about that frame's streaming
-        # step behind this frame's alloc pass (vh_reconstruction_run_ahead), as it does inside a many-frame call
-        recon.run(seq, k, 1, lookahead=True)
+    batch = 3
+    for k0 in range(0, n, batch):
+        # Three frames per call, the loop told the pose that follows (vh_reconstruction_run_ahead).  Looking at the host grid
+        # between the calls makes the grid take back the choice its worker had made for the coming frame (an observer must
+        # find the reference's state), so the first frame of every call takes the reference's order of calls and the others
+        # run pipelined: both kinds of frame, and the change-over between them, are held to the oracle.
+        k1 = min(k0 + batch, n)
+        recon.run(seq, k0, k1 - k0, lookahead=True)
         recon.synchronize()
-        # the oracle pair, in the reference's order
-        if k > 0:
-            want = ref.render(poses[k - 1])
-        p = (poses[k].reshape(4, 4) @ STREAM_POS)[:3]
-        out += og.stream_out_to_cpu(p, RADIUS, True)
-        inn += og.stream_in_to_gpu(p, RADIUS, True)
-        ref.integrate(poses[k], host[k][0], host[k][1], og.bitmask)
-        sg.stream_out_to_cpu(p, RADIUS, True)
-        sg.stream_in_to_gpu(p, RADIUS, True)
-        shadow.integrate(poses[k], host[k][0], host[k][1], sg.bitmask)
-        deterministic = deterministic and np.array_equal(canonical.block_positions(ref.hash_table()), canonical.block_positions(shadow.hash_table()))
-        if k > 0:
-            assert_maps_equal(ray.download(), want, f"cfg3 streaming frame {k}: ray cast of pose {k - 1}")
+        for k in range(k0, k1):  # the oracle pair, in the reference's order
+            if k > 0:
+                want = ref.render(poses[k - 1])
+            p = (poses[k].reshape(4, 4) @ STREAM_POS)[:3]
+            out += og.stream_out_to_cpu(p, RADIUS, True)
+            inn += og.stream_in_to_gpu(p, RADIUS, True)
+            ref.integrate(poses[k], host[k][0], host[k][1], og.bitmask)
+            sg.stream_out_to_cpu(p, RADIUS, True)
+            sg.stream_in_to_gpu(p, RADIUS, True)
+            shadow.integrate(poses[k], host[k][0], host[k][1], sg.bitmask)
+            deterministic = deterministic and np.array_equal(canonical.block_positions(ref.hash_table()), canonical.block_positions(shadow.hash_table()))
+        k = k1 - 1
+        assert_maps_equal(ray.download(), want, f"cfg3 streaming frame {k}: ray cast of pose {k - 1}")
         canonical.assert_same_scene(scene.state(), ref.state(), f"cfg3 streaming frame {k}")
         gd, gb = sorted_blocks(*grid.downloadHostBlocks())
         od, ob = sorted_blocks(*og.host_blocks())
@@ -204,8 +209,9 @@ def test_cfg3_native_loop_with_streaming_decided_ahead(E, oracle_lib, vh):
     assert st["frames"] == n
     assert (st["blocksStreamedOut"], st["blocksStreamedIn"]) == (out, inn), (st, out, inn)
     assert out > 50, "the sphere must be small enough for blocks to leave"
-    # both kinds of frame occurred: with the step known ahead to be a no-op (three launches), and with traffic
-    assert 1 <= st["streamingStepsSkipped"] < n, st
+    # (streamingStepsSkipped counts the pipelined frames in which nothing moved: three launches)
+    assert st["streamingStepsSkipped"] < n, st
+    assert st["streamingFramesPipelined"] == n - n // batch, st  # all but the first frame of every call
     sw = scene.getState()
     assert sw[T.STATE_HEAP_UNDERFLOW] == 0 and sw[T.STATE_INSERT_FAILED] == 0
     recon.close()

@@ -57,7 +57,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / a.launches
-        b = n * 8212 + 20 * cp.m_imageWidth * cp.m_imageHeight
+        b = n * 8212 + (8 if pk else 20) * cp.m_imageWidth * cp.m_imageHeight  # (bench.py stage_bytes: the packed frame is 8 B per pixel)
         out[what] = dict(us=round(us, 2), GBs=round(b / us / 1e3, 1), frac=round(b / us / 1e3 / 8000, 4))
     st = scene.getState()
     if st[9]:
@@ -76,6 +76,7 @@ def main():
         two = raw[:, 9] != 0
         out["phases_two_block_waves"] = {k: q(v[two]) for k, v in dict(staged1=ph[:, 0] - start, voxels1=ph[:, 1] - ph[:, 0], compute1=ph[:, 2] - ph[:, 1],
                                                                         staged2=ph[:, 3] - ph[:, 2], voxels2=ph[:, 4] - ph[:, 3], compute2=ph[:, 5] - ph[:, 4], rest=end - ph[:, 5]).items()}
+        out["waves_alive_at_us"] = {str(t): int(((start <= t) & (end > t)).sum()) for t in (2, 4, 6, 8, 10, 11, 12, 13, 14, 15, 16, 18)}
         np.save(os.path.join(ROOT, "gpurun_out", "wave_stamps.npy"), raw)
     print(json.dumps(dict(lib=os.path.basename(lib.LIB_PATH), blocks=n, **out)))
     scene.integrateFinish(frame, cp)

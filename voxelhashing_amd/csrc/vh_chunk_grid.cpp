@@ -97,6 +97,20 @@ CUDASceneRepChunkGrid::CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSD
     s_posCamera = { 0.0f, 0.0f, 0.0f };
     s_radius = 0.0f;
     m_bitMaskDirty = true;
+    m_plStarted = false; m_plQuit = false;
+    m_plPosted = 0; m_plDone = 0; m_plError = 0;
+    m_plDecision = { 0u, 0xffffffffu, 0 };
+    m_plDecisionValid = false;
+    m_plDecisionPos = { 0.0f, 0.0f, 0.0f };
+    m_plDecisionRadius = 0.0f;
+    m_plFrame = 0; m_plOutThisFrame = false; m_plOutTag = 0; m_plOutMost = 0;
+    for (int i = 0; i < 2; i++) { m_plInsert[i].pending = false; m_plInsert[i].tag = 0; m_plInsert[i].nIn = 0; h_plInMirror[i] = nullptr; hd_plInMirror[i] = nullptr; }
+    m_plBlocksOut = 0; m_plBlocksIn = 0; m_plTag = 0;
+    for (int i = 0; i < 2; i++) {
+        d_plOutDesc[i] = nullptr; h_plOutDesc[i] = nullptr; h_plOutBlocks[i] = nullptr; hd_plOutDesc[i] = nullptr; hd_plOutBlocks[i] = nullptr;
+        h_plOutMirror[i] = nullptr; hd_plOutMirror[i] = nullptr;
+        h_plInDesc[i] = nullptr; h_plInBlocks[i] = nullptr; d_plInDesc[i] = nullptr; d_plInBlocks[i] = nullptr;
+    }
     create(voxelExtends, gridDimensions, minGridPos, initialChunkListSize, streamingEnabled);
 }
 
@@ -146,6 +160,8 @@ void CUDASceneRepChunkGrid::create(const vh::vec3f& voxelExtends, const vh::vec3
 
 void CUDASceneRepChunkGrid::destroy()
 {
+    try { pipelineDrain(); } catch (...) {}
+    pipelineStop();
     stopMultiThreading();
     clearGrid();
     if (m_sceneRepHashSDF) (void)hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream());
@@ -195,6 +211,7 @@ void CUDASceneRepChunkGrid::startMultiThreading()
 // DSC/CUDASceneRepChunkGrid.h:262-289
 void CUDASceneRepChunkGrid::stopMultiThreading()
 {
+    pipelineDrain();
     if (!s_terminateThread) {
         s_terminateThread = true;
         hEventOutProduce.set();
@@ -328,6 +345,7 @@ void CUDASceneRepChunkGrid::resetBit(unsigned int index)
 // DSC/CUDASceneRepChunkGrid.h:306-309
 unsigned int* CUDASceneRepChunkGrid::getBitMaskGPU()
 {
+    pipelineDrain(); // (the host's copy is then complete, and the same as the device's)
     std::lock_guard<std::mutex> l(m_gridMutex);
     if (m_bitMaskDirty) {
         hipStream_t s = (hipStream_t)m_sceneRepHashSDF->getStream();
@@ -340,6 +358,7 @@ unsigned int* CUDASceneRepChunkGrid::getBitMaskGPU()
 
 void CUDASceneRepChunkGrid::getStatistics(unsigned int out[3]) const
 {
+    const_cast<CUDASceneRepChunkGrid*>(this)->pipelineDrain();
     std::lock_guard<std::mutex> l(m_gridMutex);
     unsigned int blocks = 0, chunks = 0;
     for (auto& kv : m_grid) { chunks++; blocks += kv.second->getNElements(); }
@@ -350,6 +369,7 @@ void CUDASceneRepChunkGrid::getStatistics(unsigned int out[3]) const
 
 void CUDASceneRepChunkGrid::downloadHostBlocks(std::vector<SDFBlockDesc>& descs, std::vector<vh::SDFBlock>& blocks) const
 {
+    const_cast<CUDASceneRepChunkGrid*>(this)->pipelineDrain();
     std::lock_guard<std::mutex> l(m_gridMutex);
     std::vector<unsigned int> keys;
     for (auto& kv : m_grid) keys.push_back(kv.first);
@@ -418,6 +438,7 @@ void CUDASceneRepChunkGrid::readBack(const unsigned int* d_word0, const unsigned
 // DSC/CUDASceneRepChunkGrid.cpp:55-105
 void CUDASceneRepChunkGrid::streamOutToCPUPass0GPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded)
 {
+    pipelineDrain();
     std::unique_lock<std::mutex> lock(hMutexOut, std::defer_lock);
     if (multiThreaded && s_terminateThread)
         throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamOutToCPUPass0GPU(multiThreaded): the streaming thread is not running");
@@ -499,6 +520,7 @@ unsigned int CUDASceneRepChunkGrid::probeResult()
 // streamOutToCPUPass0GPU(multiThreaded = true) of a part the probe found nothing to move out of
 void CUDASceneRepChunkGrid::streamOutNothing(const vh::vec3f& posCamera, float radius, bool useParts)
 {
+    pipelineDrain();
     if (s_terminateThread) throw vh::Error(VH_ERR_BAD_ARGUMENT, "streamOutNothing: the streaming thread is not running");
     hEventOutProduce.wait();
     {
@@ -637,6 +659,7 @@ void CUDASceneRepChunkGrid::streamInToGPU(const vh::vec3f& posCamera, float radi
 // DSC/CUDASceneRepChunkGrid.cpp:208-225
 void CUDASceneRepChunkGrid::streamInToGPUPass0CPU(const vh::vec3f& posCamera, float radius, bool useParts, bool multiThreaded)
 {
+    if (!multiThreaded) pipelineDrain(); // (called by the worker otherwise: the main thread's entry points have drained)
     std::unique_lock<std::mutex> lock(hMutexIn, std::defer_lock);
     if (multiThreaded) {
         hEventInProduce.wait();
@@ -699,6 +722,11 @@ void CUDASceneRepChunkGrid::streamInLaunches()
 // block is lost and the pool still is the union of heap and table.  They come in again with a later pass.
 void CUDASceneRepChunkGrid::takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev)
 {
+    takeBackFailedInserts(nFailed, heapCountPrev, h_SDFBlockDescInput, h_SDFBlockInput, s_nStreamdInBlocks);
+}
+
+void CUDASceneRepChunkGrid::takeBackFailedInserts(unsigned int nFailed, unsigned int heapCountPrev, const SDFBlockDesc* descs, const vh::SDFBlock* blocks, unsigned int& nIn)
+{
     HashData& hd = m_sceneRepHashSDF->getHashData();
     hipStream_t hs = (hipStream_t)m_sceneRepHashSDF->getStream();
     std::vector<unsigned int> idx(nFailed), blockIds(nFailed);
@@ -707,23 +735,32 @@ void CUDASceneRepChunkGrid::takeBackFailedInserts(unsigned int nFailed, unsigned
     checkHip(hipMemcpy(&counter, hd.d_heapCounter, sizeof(unsigned int), hipMemcpyDeviceToHost), "heapCounter");
     for (unsigned int k = 0; k < nFailed; k++) {
         const unsigned int i = idx[k];
-        if (i >= s_nStreamdInBlocks) throw vh::Error(VH_ERR_INSERT_FAILED, "stream-in: corrupt list of failed inserts");
+        if (i >= nIn) throw vh::Error(VH_ERR_INSERT_FAILED, "stream-in: corrupt list of failed inserts");
         // the heap slot the pass took for this block (chunkToGlobalHashPass1Kernel: heap[heapCountPrev - i])
         checkHip(hipMemcpy(&blockIds[k], hd.d_heap + (heapCountPrev - i), sizeof(unsigned int), hipMemcpyDeviceToHost), "heap slot");
         checkHip(hipMemsetAsync(hd.d_SDFBlocks + (size_t)blockIds[k] * VH_SDF_BLOCK_VOXELS, 0, sizeof(vh::SDFBlock), hs), "clear block");
-        integrateInChunkGrid(&h_SDFBlockDescInput[i], &h_SDFBlockInput[i], 1); // the staging copy is still there
+        integrateInChunkGrid(&descs[i], &blocks[i], 1); // the staging copy is still there
     }
     // appendHeap, DSC/VoxelUtilHashSDF.h:525-529, nFailed times
     checkHip(hipMemcpyAsync(hd.d_heap + counter + 1, blockIds.data(), sizeof(unsigned int) * nFailed, hipMemcpyHostToDevice, hs), "heap");
     counter += nFailed;
     checkHip(hipMemcpyAsync(hd.d_heapCounter, &counter, sizeof(unsigned int), hipMemcpyHostToDevice, hs), "heapCounter");
     checkHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
-    s_nStreamdInBlocks -= nFailed;
+    nIn -= nFailed;
     m_numFailedInserts += nFailed;
 }
 
 // DSC/CUDASceneRepChunkGrid.cpp:268-311
 unsigned int CUDASceneRepChunkGrid::integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts)
+{
+    return integrateInHash(posCamera, radius, useParts, h_SDFBlockDescInput, h_SDFBlockInput, d_SDFBlockDescInput, d_SDFBlockInput,
+                           m_maxNumberOfSDFBlocksIntegrateFromGlobalHash, nullptr);
+}
+
+// (the staging buffers as arguments: the pipeline has two sets of its own; chunkBit: the bit of the LAST chunk taken -- with
+// useParts the only one)
+unsigned int CUDASceneRepChunkGrid::integrateInHash(const vh::vec3f& posCamera, float radius, bool useParts, SDFBlockDesc* hDescs, vh::SDFBlock* hBlocks,
+                                                    SDFBlockDesc* dDescs, vh::SDFBlock* dBlocks, unsigned int capacity, unsigned int* chunkBit)
 {
     const vh::vec3i camChunk = worldToChunks(posCamera);
     const vh::vec3i chunkRadius = meterToNumberOfChunksCeil(radius);
@@ -744,18 +781,19 @@ unsigned int CUDASceneRepChunkGrid::integrateInHash(const vh::vec3f& posCamera, 
                 if (!isChunkInSphere(delinearizeChunkIndex(index), posCamera, radius)) continue; // is in camera range
                 ChunkDesc& c = *it->second;
                 const unsigned int nBlock = c.getNElements();
-                if (nBlock + nSDFBlocks > m_maxNumberOfSDFBlocksIntegrateFromGlobalHash) {
+                if (nBlock + nSDFBlocks > capacity) {
                     throw vh::Error(VH_ERR_STAGING_OVERFLOW,
                                     "not enough memory allocated for intermediate GPU buffer (wants to stream in more blocks than m_maxNumberOfSDFBlocksIntegrateFromGlobalHash)");
                 }
                 // copy data to GPU through pinned staging, on the worker's own stream
-                std::memcpy(h_SDFBlockDescInput + nSDFBlocks, c.getSDFBlockDescs().data(), sizeof(SDFBlockDesc) * nBlock);
-                std::memcpy(h_SDFBlockInput + nSDFBlocks, c.getSDFBlocks().data(), sizeof(vh::SDFBlock) * nBlock);
-                checkHip(hipMemcpyAsync(d_SDFBlockDescInput + nSDFBlocks, h_SDFBlockDescInput + nSDFBlocks, sizeof(SDFBlockDesc) * nBlock, hipMemcpyHostToDevice, cs), "H2D descs");
-                checkHip(hipMemcpyAsync(d_SDFBlockInput + nSDFBlocks, h_SDFBlockInput + nSDFBlocks, sizeof(vh::SDFBlock) * nBlock, hipMemcpyHostToDevice, cs), "H2D blocks");
+                std::memcpy(hDescs + nSDFBlocks, c.getSDFBlockDescs().data(), sizeof(SDFBlockDesc) * nBlock);
+                std::memcpy(hBlocks + nSDFBlocks, c.getSDFBlocks().data(), sizeof(vh::SDFBlock) * nBlock);
+                checkHip(hipMemcpyAsync(dDescs + nSDFBlocks, hDescs + nSDFBlocks, sizeof(SDFBlockDesc) * nBlock, hipMemcpyHostToDevice, cs), "H2D descs");
+                checkHip(hipMemcpyAsync(dBlocks + nSDFBlocks, hBlocks + nSDFBlocks, sizeof(vh::SDFBlock) * nBlock, hipMemcpyHostToDevice, cs), "H2D blocks");
                 // remove data from CPU
                 c.clear();
                 resetBit(index);
+                if (chunkBit) *chunkBit = index;
                 nSDFBlocks += nBlock;
                 if (useParts) {
                     checkHip(hipStreamSynchronize(cs), "hipStreamSynchronize");
@@ -771,6 +809,7 @@ unsigned int CUDASceneRepChunkGrid::integrateInHash(const vh::vec3f& posCamera, 
 // DSC/CUDASceneRepChunkGrid.cpp:313-341
 void CUDASceneRepChunkGrid::debugCheckForDuplicates() const
 {
+    const_cast<CUDASceneRepChunkGrid*>(this)->pipelineDrain();
     struct PosHash {
         size_t operator()(const std::array<int, 3>& v) const
         {
@@ -795,6 +834,280 @@ void CUDASceneRepChunkGrid::debugCheckForDuplicates() const
                 throw vh::Error(VH_ERR_BAD_ARGUMENT, "Duplicate found in streaming hash data (in grid)");
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// the streaming step without host waits (see vh.hpp)
+// ---------------------------------------------------------------------------
+
+void CUDASceneRepChunkGrid::pipelineStart()
+{
+    if (m_plStarted) return;
+    const size_t n = kPipelineBlocks;
+    for (int i = 0; i < 2; i++) {
+        checkHip(hipMalloc((void**)&d_plOutDesc[i], sizeof(SDFBlockDesc) * n), "hipMalloc");
+        checkHip(hipHostMalloc((void**)&h_plOutDesc[i], sizeof(SDFBlockDesc) * n, hipHostMallocMapped), "hipHostMalloc");
+        checkHip(hipHostMalloc((void**)&h_plOutBlocks[i], sizeof(vh::SDFBlock) * n, hipHostMallocMapped), "hipHostMalloc");
+        checkHip(hipHostGetDevicePointer((void**)&hd_plOutDesc[i], h_plOutDesc[i], 0), "hipHostGetDevicePointer");
+        checkHip(hipHostGetDevicePointer((void**)&hd_plOutBlocks[i], h_plOutBlocks[i], 0), "hipHostGetDevicePointer");
+        checkHip(hipHostMalloc((void**)&h_plOutMirror[i], sizeof(uint32_t) * 4, hipHostMallocMapped), "hipHostMalloc");
+        h_plOutMirror[i][0] = h_plOutMirror[i][1] = h_plOutMirror[i][2] = h_plOutMirror[i][3] = 0u;
+        checkHip(hipHostGetDevicePointer((void**)&hd_plOutMirror[i], h_plOutMirror[i], 0), "hipHostGetDevicePointer");
+        checkHip(hipHostMalloc((void**)&h_plInDesc[i], sizeof(SDFBlockDesc) * n, hipHostMallocDefault), "hipHostMalloc");
+        checkHip(hipHostMalloc((void**)&h_plInBlocks[i], sizeof(vh::SDFBlock) * n, hipHostMallocDefault), "hipHostMalloc");
+        checkHip(hipMalloc((void**)&d_plInDesc[i], sizeof(SDFBlockDesc) * n), "hipMalloc");
+        checkHip(hipMalloc((void**)&d_plInBlocks[i], sizeof(vh::SDFBlock) * n), "hipMalloc");
+    }
+    for (int i = 0; i < 2; i++) {
+        checkHip(hipHostMalloc((void**)&h_plInMirror[i], sizeof(uint32_t) * 4, hipHostMallocMapped), "hipHostMalloc");
+        h_plInMirror[i][0] = h_plInMirror[i][1] = h_plInMirror[i][2] = h_plInMirror[i][3] = 0u;
+        checkHip(hipHostGetDevicePointer((void**)&hd_plInMirror[i], h_plInMirror[i], 0), "hipHostGetDevicePointer");
+    }
+    m_plQuit = false;
+    m_plThread = std::thread(&CUDASceneRepChunkGrid::pipelineWorker, this);
+    m_plStarted = true;
+}
+
+void CUDASceneRepChunkGrid::pipelineStop()
+{
+    if (!m_plStarted) return;
+    {
+        std::lock_guard<std::mutex> l(m_plMutex);
+        m_plQuit = true;
+    }
+    m_plCv.notify_all();
+    if (m_plThread.joinable()) m_plThread.join();
+    m_plStarted = false;
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(d_plOutDesc[i]); (void)hipHostFree(h_plOutDesc[i]); (void)hipHostFree(h_plOutBlocks[i]); (void)hipHostFree(h_plOutMirror[i]);
+        (void)hipHostFree(h_plInDesc[i]); (void)hipHostFree(h_plInBlocks[i]); (void)hipFree(d_plInDesc[i]); (void)hipFree(d_plInBlocks[i]);
+        d_plOutDesc[i] = nullptr; h_plOutDesc[i] = nullptr; h_plOutBlocks[i] = nullptr; h_plOutMirror[i] = nullptr;
+        h_plInDesc[i] = nullptr; h_plInBlocks[i] = nullptr; d_plInDesc[i] = nullptr; d_plInBlocks[i] = nullptr;
+    }
+    for (int i = 0; i < 2; i++) { (void)hipHostFree(h_plInMirror[i]); h_plInMirror[i] = nullptr; }
+}
+
+// the worker: one job per frame
+void CUDASceneRepChunkGrid::pipelineWorker()
+{
+    (void)hipSetDevice(m_device);
+    unsigned int done = 0;
+    for (;;) {
+        PipelineJob job;
+        {
+            // frames come every 100-200 us: look at the counter for a while before going to sleep (AutoResetEvent::wait)
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned int spins = 0;
+            while (m_plPosted.load(std::memory_order_acquire) == done && !m_plQuit) {
+                if ((++spins & 0xffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+            }
+            std::unique_lock<std::mutex> l(m_plMutex);
+            m_plCv.wait(l, [&] { return m_plQuit || m_plPosted.load(std::memory_order_acquire) != done; });
+            if (m_plQuit) return;
+            job = m_plJob;
+        }
+        try {
+            if (job.haveOut) {
+                // the blocks that left: in the mapped staging buffer once the device has published the pass's tag
+                volatile uint32_t* m = h_plOutMirror[job.outSlot];
+                const auto t0 = std::chrono::steady_clock::now();
+                unsigned int spins = 0;
+                while (m[2] != job.outTag) {
+                    if ((++spins & 0xfffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                        throw vh::Error(VH_ERR_TIMEOUT, "streaming pipeline: the device did not publish its stream-out pass for 30 s");
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                const unsigned int n = m[0];
+                if (n > job.outMost)
+                    throw vh::Error(VH_ERR_STAGING_OVERFLOW, "streaming pipeline: the stream-out pass found more blocks than its probe (blocks are lost)");
+                if (n != 0) integrateInChunkGrid(h_plOutDesc[job.outSlot], h_plOutBlocks[job.outSlot], n);
+                m_plBlocksOut += n;
+            }
+            StreamDecision d = { 0u, 0xffffffffu, job.inSlot };
+            if (job.haveNext) {
+                d.nIn = integrateInHash(job.nextPos, job.nextRadius, true, h_plInDesc[job.inSlot], h_plInBlocks[job.inSlot], d_plInDesc[job.inSlot],
+                                        d_plInBlocks[job.inSlot], kPipelineBlocks, &d.chunkBit);
+            }
+            m_plDecision = d;
+        } catch (const vh::Error& e) {
+            m_plDecision = { 0u, 0xffffffffu, job.inSlot };
+            m_plError.store(e.code != 0 ? e.code : VH_ERR_BAD_ARGUMENT, std::memory_order_release);
+        }
+        done++;
+        m_plDone.store(done, std::memory_order_release);
+    }
+}
+
+bool CUDASceneRepChunkGrid::pipelineHasDecision(const vh::vec3f& posCamera, float radius) const
+{
+    return m_plStarted && m_plDecisionValid && m_plDecisionPos.x == posCamera.x && m_plDecisionPos.y == posCamera.y && m_plDecisionPos.z == posCamera.z &&
+           m_plDecisionRadius == radius;
+}
+
+// the outcome of the previous frame's insert (published by k_stream_in_commit): failures are repaired here, by the main thread
+void CUDASceneRepChunkGrid::pipelineCheckInsert(int slot, bool block)
+{
+    if (!m_plInsert[slot].pending) return;
+    volatile uint32_t* m = h_plInMirror[slot];
+    if (m[2] != m_plInsert[slot].tag) {
+        if (!block) return;
+        checkHip(hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream()), "hipStreamSynchronize");
+        if (m[2] != m_plInsert[slot].tag) throw vh::Error(-(int)hipErrorUnknown, "streaming pipeline: the device did not publish its stream-in pass");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    m_plInsert[slot].pending = false;
+    const unsigned int nFailed = m[0], heapCountPrev = m[1], exhausted = m[3];
+    unsigned int nIn = m_plInsert[slot].nIn;
+    if (exhausted) {
+        // the heap held too few free blocks: nothing was inserted, the chunk goes back into the grid (its bit is set again there;
+        // the device's copy of the mask was not touched)
+        integrateInChunkGrid(h_plInDesc[slot], h_plInBlocks[slot], nIn);
+        m_numFailedInserts += nIn;
+        nIn = 0;
+    } else if (nFailed != 0) {
+        checkHip(hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream()), "hipStreamSynchronize");
+        takeBackFailedInserts(nFailed, heapCountPrev, h_plInDesc[slot], h_plInBlocks[slot], nIn);
+        // the blocks that went back set their chunk's bit in the host's copy; the device's copy had it cleared by the pass.
+        // (The device is idle and the worker has no job: the host's copy is complete.)
+        std::lock_guard<std::mutex> l(m_gridMutex);
+        checkHip(hipMemcpy(d_bitMask, m_bitMask.data(), sizeof(unsigned int) * m_bitMask.size(), hipMemcpyHostToDevice), "bit mask");
+        m_bitMaskDirty = false;
+    }
+    m_plBlocksIn += nIn;
+}
+
+CUDASceneRepChunkGrid::StreamDecision CUDASceneRepChunkGrid::pipelineDecision()
+{
+    if (!m_plStarted || !m_plDecisionValid) throw vh::Error(VH_ERR_BAD_ARGUMENT, "pipelineDecision(): pipelineAsk() has not asked for one");
+    // the worker has had the rest of the previous frame's device time
+    const unsigned int posted = m_plPosted.load(std::memory_order_acquire);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned int spins = 0;
+    while (m_plDone.load(std::memory_order_acquire) != posted) {
+        if ((++spins & 0xfffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(40))
+            throw vh::Error(VH_ERR_TIMEOUT, "streaming pipeline: the worker thread did not answer for 40 s");
+    }
+    const int err = m_plError.exchange(0, std::memory_order_acq_rel);
+    if (err != 0) {
+        m_plDecisionValid = false;
+        throw vh::Error(err, std::string("streaming pipeline (worker): ") + vh_error_string(err));
+    }
+    m_plDecisionValid = false; // (consumed)
+    pipelineCheckInsert(0, false);
+    pipelineCheckInsert(1, false);
+    return m_plDecision;
+}
+
+bool CUDASceneRepChunkGrid::pipelineStreamOut(const vh::vec3f& posCamera, float radius, bool useParts, unsigned int mostBlocks)
+{
+    if (mostBlocks > (unsigned int)kPipelineBlocks) return false;
+    pipelineStart();
+    s_posCamera = posCamera;
+    s_radius = radius;
+    const int slot = (int)(m_plFrame & 1u);
+    m_plOutThisFrame = false;
+    if (mostBlocks != 0u) {
+        const HashParams& hp = m_sceneRepHashSDF->getHashParams();
+        HashData& hd = m_sceneRepHashSDF->getHashData();
+        vhStream_t stream = m_sceneRepHashSDF->getStream();
+        const int32_t token = m_sceneRepHashSDF->nextLockToken(); // = resetHashBucketMutexCUDA
+        m_sceneRepHashSDF->noteTableEdited();
+        const unsigned int numEntries = hp.m_hashNumBuckets * hp.m_hashBucketSize;
+        unsigned int threadsPerPart = (numEntries + m_streamOutParts - 1) / m_streamOutParts;
+        if (!useParts) threadsPerPart = numEntries;
+        const unsigned int start = useParts ? m_currentPart * threadsPerPart : 0;
+        const float cam[3] = { posCamera.x, posCamera.y, posCamera.z };
+        // pass 1 lists into device memory (pass 2 reads the list back); pass 2 writes blocks AND descriptors to the host
+        check(vh_stream_out_device(&hd, &hp, threadsPerPart, start, radius, cam, d_SDFBlockCounter, d_plOutDesc[slot], (VhVoxel*)hd_plOutBlocks[slot],
+                                   mostBlocks, token, d_bitMask, stream), "vh_stream_out_device");
+        checkHip(hipMemcpyAsync(h_plOutDesc[slot], d_plOutDesc[slot], sizeof(SDFBlockDesc) * mostBlocks, hipMemcpyDeviceToHost, (hipStream_t)stream), "descs to host");
+        m_plOutTag = ++m_plTag ? m_plTag : ++m_plTag;
+        m_plOutMost = mostBlocks;
+        check(vh_publish_count(d_SDFBlockCounter, hd_plOutMirror[slot], m_plOutTag, stream), "vh_publish_count");
+        m_plOutThisFrame = true;
+    } else {
+        (void)m_sceneRepHashSDF->nextLockToken(); // (the pass draws one: keep the sequence of tokens the same)
+    }
+    if (useParts) m_currentPart = (m_currentPart + 1) % m_streamOutParts;
+    s_nStreamdOutBlocks = 0; // (known to the worker only)
+    return true;
+}
+
+void CUDASceneRepChunkGrid::pipelineStreamIn(const StreamDecision& d)
+{
+    s_nStreamdInBlocks = d.nIn;
+    if (d.nIn == 0u) return;
+    pipelineCheckInsert(d.slot, true); // (the slot's previous insert, two frames back: long done)
+    const HashParams& hp = m_sceneRepHashSDF->getHashParams();
+    HashData& hd = m_sceneRepHashSDF->getHashData();
+    const int32_t token = m_sceneRepHashSDF->nextLockToken();
+    m_sceneRepHashSDF->noteTableEdited();
+    const uint32_t tag = ++m_plTag ? m_plTag : ++m_plTag;
+    check(vh_stream_in_device(&hd, &hp, d.nIn, d_plInDesc[d.slot], (const VhVoxel*)d_plInBlocks[d.slot], token, d_insertFailed, d_bitMask, d.chunkBit,
+                              hd_plInMirror[d.slot], tag, m_sceneRepHashSDF->getStream()), "vh_stream_in_device");
+    m_plInsert[d.slot].pending = true; m_plInsert[d.slot].tag = tag; m_plInsert[d.slot].nIn = d.nIn;
+}
+
+void CUDASceneRepChunkGrid::pipelineAsk(bool haveNext, const vh::vec3f& nextPosCamera, float nextRadius)
+{
+    pipelineStart();
+    if (!haveNext && !m_plOutThisFrame) { m_plFrame++; return; } // nothing for the worker to do
+    {
+        std::lock_guard<std::mutex> l(m_plMutex);
+        m_plJob.haveOut = m_plOutThisFrame;
+        m_plJob.outTag = m_plOutTag;
+        m_plJob.outMost = m_plOutMost;
+        m_plJob.outSlot = (int)(m_plFrame & 1u);
+        m_plJob.haveNext = haveNext;
+        m_plJob.inSlot = (int)((m_plFrame + 1u) & 1u);
+        m_plJob.nextPos = nextPosCamera;
+        m_plJob.nextRadius = nextRadius;
+        m_plPosted.fetch_add(1u, std::memory_order_release);
+    }
+    m_plCv.notify_one();
+    m_plOutThisFrame = false;
+    m_plDecisionValid = haveNext;
+    m_plDecisionPos = nextPosCamera;
+    m_plDecisionRadius = nextRadius;
+    m_plFrame++;
+}
+
+void CUDASceneRepChunkGrid::pipelineReturn(const StreamDecision& d, const vh::vec3f& posCamera, float radius)
+{
+    m_plDecision = d;
+    m_plDecisionValid = true;
+    m_plDecisionPos = posCamera;
+    m_plDecisionRadius = radius;
+}
+
+void CUDASceneRepChunkGrid::pipelineDrain(bool undo)
+{
+    if (!m_plStarted) return;
+    const unsigned int posted = m_plPosted.load(std::memory_order_acquire);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned int spins = 0;
+    while (m_plDone.load(std::memory_order_acquire) != posted) {
+        if ((++spins & 0xfffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(40))
+            throw vh::Error(VH_ERR_TIMEOUT, "streaming pipeline: the worker thread did not finish for 40 s");
+    }
+    if (undo && m_plDecisionValid) {
+        // a choice nobody will use: the chunk goes back into the grid (its bit with it; the device's copy still has it set)
+        m_plDecisionValid = false;
+        if (m_plDecision.nIn != 0u) integrateInChunkGrid(h_plInDesc[m_plDecision.slot], h_plInBlocks[m_plDecision.slot], m_plDecision.nIn);
+    }
+    pipelineCheckInsert(0, undo);
+    pipelineCheckInsert(1, undo);
+    const int err = m_plError.exchange(0, std::memory_order_acq_rel);
+    if (err != 0) throw vh::Error(err, std::string("streaming pipeline (worker): ") + vh_error_string(err));
+}
+
+void CUDASceneRepChunkGrid::pipelineTotals(unsigned long long* blocksOut, unsigned long long* blocksIn)
+{
+    pipelineDrain(false);
+    pipelineCheckInsert(0, true);
+    pipelineCheckInsert(1, true);
+    if (blocksOut) *blocksOut = m_plBlocksOut.load();
+    if (blocksIn) *blocksIn = m_plBlocksIn.load();
 }
 
 // ---------------------------------------------------------------------------

@@ -3104,6 +3104,60 @@ __global__ __launch_bounds__(64) void k_stream_out_pass1(VhHashData hd, VhHashPa
     }
 }
 
+// The chunk of a block, as the host's integrateInChunkGrid works it out (worldToChunks of the block's world position,
+// linearizeChunkPos; DSC/CUDASceneRepChunkGrid.cpp:126-153, .h:570-598): the index of its bit in the bit mask, or
+// 0xffffffff for a chunk outside the grid (the host drops such a block: "Chunk out of bounds")
+VHD uint32_t chunk_bit_of_block(const VhHashParams& hp, I3 blk)
+{
+    const F3 pw = block_to_world(hp.m_virtualVoxelSize, blk);
+    const F3 p = mk3(pw.x / hp.m_streamingVoxelExtents[0], pw.y / hp.m_streamingVoxelExtents[1], pw.z / hp.m_streamingVoxelExtents[2]);
+    const I3 c = mki3(f2i(p.x + (float)signi(p.x) * 0.5f), f2i(p.y + (float)signi(p.y) * 0.5f), f2i(p.z + (float)signi(p.z) * 0.5f));
+    const int qx = c.x - hp.m_streamingMinGridPos[0], qy = c.y - hp.m_streamingMinGridPos[1], qz = c.z - hp.m_streamingMinGridPos[2];
+    if (qx < 0 || qy < 0 || qz < 0 || qx >= hp.m_streamingGridDimensions[0] || qy >= hp.m_streamingGridDimensions[1] || qz >= hp.m_streamingGridDimensions[2])
+        return 0xffffffffu;
+    return (uint32_t)(qz * hp.m_streamingGridDimensions[0] * hp.m_streamingGridDimensions[1] + qy * hp.m_streamingGridDimensions[0] + qx);
+}
+
+// k_stream_out_pass1 that also keeps the DEVICE's copy of the bit mask: the bit of every block's chunk is set here, where
+// the block leaves, instead of by the host a round trip later (the host sets the same bit in its own copy when the block
+// arrives; the frame's alloc pass, which reads the mask, then need not wait for the host)
+__global__ __launch_bounds__(64) void k_stream_out_pass1_bits(VhHashData hd, VhHashParams hp, uint32_t start, float radius,
+                                                              float cx, float cy, float cz, uint32_t* outCounter,
+                                                              VhSDFBlockDesc* out, uint32_t capacity, int32_t lockToken, uint32_t* bitMask)
+{
+    const uint32_t ne = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x + start;
+    if (idx >= ne) return;
+    VhHashEntry* e = &hd.d_hash[idx];
+    const int4 q = load_quad(e);
+    const uint32_t off = e->offset;
+    const I3 pos = mki3(q.x, q.y, q.z);
+    const F3 pw = block_to_world(hp.m_virtualVoxelSize, pos);
+    const F3 df = mk3(pw.x - cx, pw.y - cy, pw.z - cz);
+    const float d = sqrtf(dot3(df, df));
+    if (q.w != VH_FREE_ENTRY && d >= radius) {
+        bool emit = false;
+        if (off != 0u || hash_pos(hp.m_hashNumBuckets, pos) != idx / VH_HASH_BUCKET_SIZE) {
+            emit = delete_hash_entry_element(hd, hp, pos, lockToken);
+        } else {
+            append_heap(hd, (uint32_t)q.w / VH_SDF_BLOCK_VOXELS);
+            delete_hash_entry(e);
+            bucket_dec(hd, idx);
+            emit = true;
+        }
+        if (emit) {
+            const uint32_t addr = atomicAdd(outCounter, 1u);
+            if (addr < capacity) {
+                VhSDFBlockDesc dsc;
+                dsc.pos[0] = q.x; dsc.pos[1] = q.y; dsc.pos[2] = q.z; dsc.ptr = q.w;
+                out[addr] = dsc;
+                const uint32_t bit = chunk_bit_of_block(hp, pos);
+                if (bitMask && bit != 0xffffffffu) atomicOr(&bitMask[bit >> 5], 1u << (bit & 31u));
+            }
+        }
+    }
+}
+
 // The same scan without the deletes: how many blocks of the part would the pass move out?  (A frame loop that knows its
 // poses ahead asks this a frame early -- after that frame's alloc, the last pass that adds blocks -- and keeps the
 // whole streaming step out of the next frame's launches when the answer is none: Reconstruction::frame.)
@@ -3142,6 +3196,69 @@ __global__ __launch_bounds__(256) void k_stream_out_pass2(VhHashData hd, const V
     uint4* src = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + threadIdx.x;
     reinterpret_cast<uint4*>(out)[(size_t)b * 256 + threadIdx.x] = *src;
     *src = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// k_stream_out_pass2 for a caller that has not read the count: as many workgroups as blocks there can be at most, each
+// looks the count up
+__global__ __launch_bounds__(256) void k_stream_out_pass2_counted(VhHashData hd, const VhSDFBlockDesc* descs, VhVoxel* out, const uint32_t* counter, uint32_t capacity)
+{
+    const uint32_t b = blockIdx.x, n = min(*counter, capacity);
+    if (b >= n) return;
+    const int ptr = __builtin_amdgcn_readfirstlane(descs[b].ptr);
+    uint4* src = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + threadIdx.x;
+    reinterpret_cast<uint4*>(out)[(size_t)b * 256 + threadIdx.x] = *src;
+    *src = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// {count of the pass, 0, tag} into mapped host memory, behind the pass's copies in the stream: a host thread that sees the
+// tag finds the copied blocks in its staging buffer
+__global__ void k_publish_count(const uint32_t* counter, uint32_t* mapped, uint32_t tag)
+{
+    mapped[0] = *counter;
+    mapped[1] = 0u;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(&mapped[2], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The stream-in pass for a caller that does not read the heap counter back: chunkToGlobalHashPass1Kernel / Pass2Kernel
+// with the counter looked up on the device, the chunk's bit cleared in the device's copy of the bit mask, and a third
+// launch that takes the blocks off the heap and tells the host (mapped memory) how it went:
+//   {blocks that found no slot, heap counter before the pass, 1 if the heap held too few free blocks (nothing was done), tag}
+__global__ __launch_bounds__(64) void k_stream_in_pass1_dev(VhHashData hd, VhHashParams hp, uint32_t n, const VhSDFBlockDesc* descs, int32_t lockToken,
+                                                            uint32_t* failed, uint32_t* bitMask, uint32_t chunkBit)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t heapCountPrev = hd.d_heapCounter[0];
+    if (n > heapCountPrev + 1u) return; // (k_stream_in_commit reports it; the host puts the blocks back into its grid)
+    if (i == 0u && bitMask && chunkBit != 0xffffffffu) atomicAnd(&bitMask[chunkBit >> 5], ~(1u << (chunkBit & 31u)));
+    const uint32_t ptr = hd.d_heap[heapCountPrev - i] * VH_SDF_BLOCK_VOXELS;
+    const VhSDFBlockDesc dsc = descs[i];
+    if (!insert_hash_entry(hd, hp, mki3(dsc.pos[0], dsc.pos[1], dsc.pos[2]), (int)ptr, lockToken)) {
+        atomicAdd(&hd.d_state[VH_STATE_INSERT_FAILED], 1u);
+        failed[1u + atomicAdd(&failed[0], 1u)] = i;
+    }
+}
+__global__ __launch_bounds__(256) void k_stream_in_pass2_dev(VhHashData hd, uint32_t n, const VhVoxel* blocks)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const uint32_t heapCountPrev = hd.d_heapCounter[0];
+    if (n > heapCountPrev + 1u) return;
+    const uint32_t ptr = hd.d_heap[heapCountPrev - b] * VH_SDF_BLOCK_VOXELS;
+    *(reinterpret_cast<uint4*>(&hd.d_SDFBlocks[ptr]) + threadIdx.x) = reinterpret_cast<const uint4*>(blocks)[(size_t)b * 256 + threadIdx.x];
+}
+__global__ void k_stream_in_commit(VhHashData hd, uint32_t n, const uint32_t* failed, uint32_t* mapped, uint32_t tag)
+{
+    const uint32_t heapCountPrev = hd.d_heapCounter[0];
+    const bool exhausted = n > heapCountPrev + 1u;
+    if (!exhausted) hd.d_heapCounter[0] = heapCountPrev - n;
+    else atomicAdd(&hd.d_state[VH_STATE_HEAP_UNDERFLOW], 1u);
+    mapped[0] = failed[0];
+    mapped[1] = heapCountPrev;
+    mapped[3] = exhausted ? 1u : 0u;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(&mapped[2], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // chunkToGlobalHashPass1Kernel :143-160
@@ -3794,8 +3911,12 @@ int vh_stream_out_probe(const VhHashData* hd, const VhHashParams* hp, uint32_t t
                         const float camPos[3], uint32_t* d_counter, uint32_t* d_mapped, uint32_t tag, vhStream_t stream)
 {
     if (!hd || !hp || !camPos || !d_counter || !d_mapped) return VH_ERR_BAD_ARGUMENT;
-    if (threadsPerPart != 0)
-        k_stream_out_probe<<<cdiv(threadsPerPart, 256), 256, 0, (hipStream_t)stream>>>(*hd, *hp, start, threadsPerPart, radius, camPos[0], camPos[1], camPos[2], d_counter);
+    if (threadsPerPart != 0) {
+        // (the pass itself runs whole workgroups of 64: it looks at up to 63 entries beyond its part, and so must its probe --
+        // the count is used as an upper bound)
+        const uint32_t scanned = cdiv(threadsPerPart, 64) * 64u;
+        k_stream_out_probe<<<cdiv(scanned, 256), 256, 0, (hipStream_t)stream>>>(*hd, *hp, start, scanned, radius, camPos[0], camPos[1], camPos[2], d_counter);
+    }
     k_publish_and_clear<<<1, 1, 0, (hipStream_t)stream>>>(d_counter, d_mapped, tag);
     return vh_last_launch_error();
 }
@@ -3807,6 +3928,43 @@ int vh_stream_out_pass2(const VhHashData* hd, const VhHashParams* hp, const VhSD
     if (!hd || !d_descs || !d_output) return VH_ERR_BAD_ARGUMENT;
     if (nSDFBlocks == 0) return VH_OK;
     k_stream_out_pass2<<<nSDFBlocks, 256, 0, (hipStream_t)stream>>>(*hd, d_descs, d_output, nSDFBlocks);
+    return vh_last_launch_error();
+}
+
+int vh_stream_out_device(const VhHashData* hd, const VhHashParams* hp, uint32_t threadsPerPart, uint32_t start, float radius,
+                         const float camPos[3], uint32_t* d_outputCounter, VhSDFBlockDesc* d_descs, VhVoxel* d_blocks,
+                         uint32_t mostBlocks, int32_t lockToken, uint32_t* d_bitMask, vhStream_t stream)
+{
+    if (!hd || !hp || !camPos || !d_outputCounter || !d_descs || !d_blocks) return VH_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    VH_HIP(hipMemsetAsync(d_outputCounter, 0, sizeof(uint32_t), s));
+    if (threadsPerPart == 0 || mostBlocks == 0) return VH_OK;
+    k_stream_out_pass1_bits<<<cdiv(threadsPerPart, 64), 64, 0, s>>>(*hd, *hp, start, radius, camPos[0], camPos[1], camPos[2], d_outputCounter, d_descs,
+                                                                     mostBlocks, lockToken, d_bitMask);
+    k_stream_out_pass2_counted<<<mostBlocks, 256, 0, s>>>(*hd, d_descs, d_blocks, d_outputCounter, mostBlocks);
+    return vh_last_launch_error();
+}
+
+int vh_publish_count(const uint32_t* d_counter, uint32_t* d_mapped, uint32_t tag, vhStream_t stream)
+{
+    if (!d_counter || !d_mapped) return VH_ERR_BAD_ARGUMENT;
+    k_publish_count<<<1, 1, 0, (hipStream_t)stream>>>(d_counter, d_mapped, tag);
+    return vh_last_launch_error();
+}
+
+int vh_stream_in_device(const VhHashData* hd, const VhHashParams* hp, uint32_t n, const VhSDFBlockDesc* d_descs, const VhVoxel* d_blocks,
+                        int32_t lockToken, uint32_t* d_failed, uint32_t* d_bitMask, uint32_t chunkBit, uint32_t* d_mapped, uint32_t tag,
+                        vhStream_t stream)
+{
+    if (!hd || !hp || !d_descs || !d_blocks || !d_failed || !d_mapped) return VH_ERR_BAD_ARGUMENT;
+    if (hp->m_hashNumBuckets < 2) return VH_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    VH_HIP(hipMemsetAsync(d_failed, 0, sizeof(uint32_t), s));
+    if (n != 0) {
+        k_stream_in_pass1_dev<<<cdiv(n, 64), 64, 0, s>>>(*hd, *hp, n, d_descs, lockToken, d_failed, d_bitMask, chunkBit);
+        k_stream_in_pass2_dev<<<n, 256, 0, s>>>(*hd, n, d_blocks);
+    }
+    k_stream_in_commit<<<1, 1, 0, s>>>(*hd, n, d_failed, d_mapped, tag);
     return vh_last_launch_error();
 }
 

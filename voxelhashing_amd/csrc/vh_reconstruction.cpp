@@ -80,6 +80,8 @@ Reconstruction::Reconstruction(CUDASceneRepHashSDF* sceneRep, CUDARayCastSDF* ra
     : m_sceneRep(sceneRep), m_rayCast(rayCast), m_chunkGrid(chunkGrid), m_cp(cp), m_opt(options), m_frameNumber(0), m_copyStream(nullptr), m_copyStream2(nullptr)
 {
     m_debugFailRender = 0;
+    m_pipelineOutSeen = m_pipelineInSeen = 0;
+    if (chunkGrid) chunkGrid->pipelineTotals(&m_pipelineOutSeen, &m_pipelineInSeen);
     if (!sceneRep) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: no scene");
     if (options.s_streamingEnabled && !chunkGrid) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: streaming needs a chunk grid");
     if (options.s_renderEnabled && !rayCast) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: rendering needs a ray caster");
@@ -133,6 +135,7 @@ void Reconstruction::synchronize()
     if (m_copyStream2) checkHip(hipStreamSynchronize((hipStream_t)m_copyStream2), "hipStreamSynchronize");
     // the scene's side stream joins the main stream in integrateFinish(): the main stream is the last to finish
     checkHip(hipStreamSynchronize((hipStream_t)m_sceneRep->getStream()), "hipStreamSynchronize");
+    if (m_chunkGrid) m_chunkGrid->pipelineDrain(false); // (the grid's worker has taken in what the last frame moved out; its choice for the next frame stands)
 }
 
 void Reconstruction::reset()
@@ -161,6 +164,14 @@ const ReconstructionStats& Reconstruction::getStats()
     }
     // the scene's status words: an empty voxel pool or a failed stream-in insert is raised on the device; this is where a
     // caller of the loop gets to see it (a blocking 64-byte read-back: get_stats() is not for the inside of a timed region)
+    if (m_chunkGrid) { // what the streaming pipeline moved (its worker counts the blocks that left when they arrive)
+        unsigned long long out = 0, in = 0;
+        m_chunkGrid->pipelineTotals(&out, &in);
+        m_stats.blocksStreamedOut += out - m_pipelineOutSeen;
+        m_stats.blocksStreamedIn += in - m_pipelineInSeen;
+        m_pipelineOutSeen = out;
+        m_pipelineInSeen = in;
+    }
     uint32_t state[VH_STATE_WORDS];
     m_sceneRep->getState(state);
     m_stats.heapUnderflows = state[VH_STATE_HEAP_UNDERFLOW];
@@ -275,49 +286,44 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     const bool threaded = streaming && !m_opt.s_offlineProcessing && !m_chunkGrid->getTerminatedThread();
     const vh::vec3f p = transformation.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
 
-    // The streaming step of this frame (:881-900), decided ahead where that is possible.  The reference runs it between
-    // the ray cast of the previous pose and this frame's alloc, and blocks on two counters in it; alloc could therefore
-    // not ride in the ray caster's launch.  But in most frames nothing streams, and whether anything will is known
-    // early: the previous frame has asked the device (a count-only run of the stream-out scan for THIS frame's sphere
-    // and part, after its own alloc -- nothing adds blocks between there and here, so the count can only be too large),
-    // and what comes in is the worker thread's business on the host.  With nothing going out, nothing coming in and
-    // an unchanged bit mask the step is a no-op, and the frame runs as it does without streaming: three launches.
-    enum Step { kFull, kAfterOut, kNothing } step = kFull;
-    unsigned int nIn = 0;
-    // Two hand-offs of this function are in two halves with other calls in between (the ray cast, which may throw):
-    // streamInWait() ... streamInFinish() holds the worker's mutex and owes it an event -- a later stopMultiThreading(),
-    // reset() or destruction of the grid would wait for that worker forever -- and integrateAhead() ... integrateFinish()
-    // leaves the scene refusing every integrate() until it is finished.  On unwind both are put back.
-    struct Unwind {
-        CUDASceneRepChunkGrid* grid;
+    // The streaming step of this frame (:881-900).  The reference runs it between the ray cast of the previous pose and this
+    // frame's alloc as a chain of host <-> device round trips (two counters read back, the blocks that left put into the host
+    // grid before the bit mask for alloc is known, the chunk that comes in chosen after that), so alloc could not ride in the
+    // ray caster's launch and the host could not enqueue past it.  With the next pose known a frame ahead (the sequence
+    // comes from a file) the step runs without a host wait (CUDASceneRepChunkGrid's pipeline, vh.hpp):
+    //   * how many blocks leave at most was asked of the device a frame early (a count-only run of the stream-out scan for
+    //     THIS frame's sphere and part, behind the previous frame's alloc: nothing adds blocks between there and here);
+    //   * the chunk that comes in was chosen and uploaded by the grid's worker while the device worked on the previous frame;
+    //   * the counts stay on the device, the device keeps its own copy of the bit mask.
+    // A frame in which nothing leaves and nothing comes in is then three launches, like a frame without streaming (alloc
+    // rides in the ray caster's launch, reading the device's bit mask); a frame with traffic is the reference's order of
+    // launches, enqueued without waiting.  Without the answers (first frame, next pose unknown, a pass too large for the
+    // pipeline's staging) the frame takes the reference's order of calls.
+    enum Step { kFull, kPipelined } step = kFull;
+    unsigned int mostOut = 0;
+    CUDASceneRepChunkGrid::StreamDecision choice = { 0u, 0xffffffffu, 0 };
+    struct Unwind { // (integrateAhead() ... integrateFinish() with the ray cast in between: a throw must not leave the scene refusing every integrate())
         CUDASceneRepHashSDF* scene;
-        bool streamIn = false, ahead = false;
-        ~Unwind()
-        {
-            if (streamIn) { try { grid->streamInAbort(); } catch (...) {} }
-            if (ahead) scene->abortAhead();
-        }
-    } unwind{ m_chunkGrid, m_sceneRep };
-    if (threaded && m_probePending && std::memcmp(m_probePose, f.rigidTransform, sizeof(m_probePose)) == 0) {
+        bool ahead = false;
+        ~Unwind() { if (ahead) scene->abortAhead(); }
+    } unwind{ m_sceneRep };
+    const bool pipelined = threaded && m_opt.s_allocAhead && m_opt.s_integrationEnabled;
+    if (pipelined && m_probePending && std::memcmp(m_probePose, f.rigidTransform, sizeof(m_probePose)) == 0 &&
+        m_chunkGrid->pipelineHasDecision(p, m_opt.s_streamingRadius)) {
         const double t0 = now();
-        if (m_chunkGrid->probeResult() == 0) {
-            m_chunkGrid->streamOutNothing(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts);
-            nIn = m_chunkGrid->streamInWait();
-            unwind.streamIn = true;
-            step = (nIn == 0 && !m_chunkGrid->bitMaskDirty()) ? kNothing : kAfterOut;
-            if (step == kNothing) {
-                unwind.streamIn = false; // (streamInFinish() cleans up after itself)
-                m_chunkGrid->streamInFinish(); // (launches nothing; hands the buffers back to the worker)
-                m_stats.streamingStepsSkipped++;
-            }
+        mostOut = m_chunkGrid->probeResult();
+        if (mostOut <= m_chunkGrid->pipelineCapacity()) {
+            choice = m_chunkGrid->pipelineDecision();
+            step = kPipelined;
         }
         m_stats.hostWaitSeconds += now() - t0;
     }
     m_probePending = false;
+    const bool quiet = step == kPipelined && mostOut == 0u && choice.nIn == 0u;
 
-    const bool ahead = m_opt.s_allocAhead && m_opt.s_integrationEnabled && (!streaming || step == kNothing);
+    const bool ahead = m_opt.s_allocAhead && m_opt.s_integrationEnabled && (!streaming || quiet);
     const unsigned int* d_bitMask = nullptr;
-    if (streaming && step == kNothing) d_bitMask = m_chunkGrid->getBitMaskGPU(); // (clean: no upload)
+    if (streaming && step == kPipelined) d_bitMask = m_chunkGrid->getBitMaskDevice(); // (kept by the passes themselves: no upload)
     // :750-751 (the pose the scene holds is the previous frame's)
     const vh::mat4f renderTransform = m_sceneRep->getLastRigidTransform();
     VhFrameJob* job = nullptr;
@@ -325,22 +331,32 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
         job = m_sceneRep->integrateAhead(transformation, cam, m_cp, d_bitMask);
         unwind.ahead = true;
     }
-    if (m_frameNumber > 0 && m_opt.s_renderEnabled) {
-        if (m_debugFailRender && --m_debugFailRender == 0) throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: injected failure of the ray cast (vh_reconstruction_debug_fail_render)"); // :750 "getFrameNumber() > 1" with frames counted from 1
+    if (m_frameNumber > 0 && m_opt.s_renderEnabled) { // :750 "getFrameNumber() > 1" with frames counted from 1
+        if (m_debugFailRender && --m_debugFailRender == 0) {
+            // (the choice for this frame has been taken off the worker: hand it back before leaving)
+            if (step == kPipelined) m_chunkGrid->pipelineReturn(choice, p, m_opt.s_streamingRadius);
+            throw vh::Error(VH_ERR_BAD_ARGUMENT, "Reconstruction: injected failure of the ray cast (vh_reconstruction_debug_fail_render)");
+        }
         const unsigned int used0 = m_rayCast->getNumSplatsMadeAheadUsed();
-        m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform, job); // :763
+        try {
+            m_rayCast->render(m_sceneRep->getHashData(), m_sceneRep->getHashParams(), m_cp, renderTransform, job); // :763
+        } catch (...) {
+            if (step == kPipelined) m_chunkGrid->pipelineReturn(choice, p, m_opt.s_streamingRadius);
+            throw;
+        }
         m_stats.splatsMadeAheadUsed += m_rayCast->getNumSplatsMadeAheadUsed() - used0;
         if (job && job->allocLaunched && job->compactifyLaunched) m_stats.framesWithRiders++;
     }
 
-    if (streaming && step != kNothing) { // :881-900
+    if (streaming && step == kPipelined) {
+        (void)m_chunkGrid->pipelineStreamOut(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, mostOut);
+        m_chunkGrid->pipelineStreamIn(choice);
+        m_stats.streamingFramesPipelined++;
+        if (quiet) m_stats.streamingStepsSkipped++;
+    } else if (streaming) { // :881-900
         const double t0 = now();
         unsigned int nStreamedBlocks = 0;
-        if (step == kAfterOut) {
-            unwind.streamIn = false;
-            m_chunkGrid->streamInFinish();
-            m_stats.blocksStreamedIn += nIn;
-        } else if (m_opt.s_offlineProcessing) {
+        if (m_opt.s_offlineProcessing) {
             for (unsigned int i = 0; i < m_sceneRep->getOptions().s_streamingOutParts; i++) {
                 m_chunkGrid->streamOutToCPU(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, nStreamedBlocks);
                 m_stats.blocksStreamedOut += nStreamedBlocks;
@@ -363,11 +379,14 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     }
 
     // the question for the next frame, behind this frame's alloc
-    const bool ask = threaded && m_opt.s_allocAhead && m_opt.s_integrationEnabled && next && next->depth && poseValid(next->rigidTransform);
-    auto askNow = [&]() {
+    const bool ask = pipelined && next && next->depth && poseValid(next->rigidTransform);
+    vh::vec3f np = { 0.0f, 0.0f, 0.0f };
+    if (ask) {
         vh::mat4f nt;
         std::memcpy(nt.m, next->rigidTransform, sizeof(nt.m));
-        const vh::vec3f np = nt.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
+        np = nt.transformPoint({ m_opt.s_streamingPos[0], m_opt.s_streamingPos[1], m_opt.s_streamingPos[2] });
+    }
+    auto askNow = [&]() {
         m_chunkGrid->probeStreamOut(np, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts);
         std::memcpy(m_probePose, next->rigidTransform, sizeof(m_probePose));
         m_probePending = true;
@@ -383,6 +402,8 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
         m_sceneRep->setLastRigidTransformAndCompactify(transformation, m_cp); // :907
     }
     if (ask && !allocIsIn) askNow();
+    // the worker's job: take in what this frame's stream-out pass moves, choose and upload what comes in at the next frame
+    if (pipelined && (ask || step == kPipelined)) m_chunkGrid->pipelineAsk(ask, np, m_opt.s_streamingRadius);
     m_frameNumber++;
     m_stats.frames++;
 }

@@ -62,6 +62,9 @@ PROTOTYPES = {
     "vh_compute_normals_co2": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, P(T.FrameJob), P(T.RayCastParams), _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, _VP]),
     "vh_stream_out_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, C.c_uint32, C.c_int32, _VP]),
     "vh_stream_out_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), _VP, _VP, C.c_uint32, _VP]),
+    "vh_stream_out_device": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, C.c_float, _F16, _VP, _VP, _VP, C.c_uint32, C.c_int32, _VP, _VP]),
+    "vh_publish_count": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
+    "vh_stream_in_device": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, _VP, _VP, C.c_int32, _VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP]),
     "vh_stream_in_pass1": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP]),
     "vh_stream_in_pass1_report": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, C.c_int32, _VP, _VP]),
     "vh_stream_in_pass2": (C.c_int, [P(T.HashData), P(T.HashParams), C.c_uint32, C.c_uint32, _VP, _VP, _VP]),

@@ -258,6 +258,7 @@ class ReconstructionStats(C.Structure):
         ("failedInserts", C.c_uint64),
         ("framesWithRiders", C.c_uint64),
         ("splatsMadeAheadUsed", C.c_uint64),
+        ("streamingFramesPipelined", C.c_uint64),
     ]
 
 
