@@ -226,3 +226,59 @@ def test_blocks_that_find_no_slot_go_back_to_the_host_grid(E, tmp_path):
     assert s["voxels"].tobytes() == np.ascontiguousarray(vox[order]).tobytes()
     assert s["heap_free"] == 64 - 14
     assert scene.debugHash()["duplicates"] == 0
+
+
+@pytest.mark.timeout(300)
+def test_blocks_that_find_no_slot_in_a_pipelined_frame_go_back_too(E, tmp_path):
+    """The same crowded chunk, brought in by the native loop's pipelined streaming step (the grid's worker chooses and uploads
+    the chunk a frame ahead, the insert runs without the host reading anything back): the pass reports the blocks that found
+    no slot through mapped memory, the loop repairs them a frame later (back into the host grid, their SDF blocks back on the
+    heap, the bit mask set right again), and later frames bring them in.  Nothing lost, nothing leaked, and the loop never
+    waited for the device in the frames in between."""
+    rng = np.random.default_rng(7)
+    ext, dims, minp = (4.0, 4.0, 4.0), (9, 9, 9), (-4, -4, -4)
+    hp, cp, rp = small_config(64, 48, num_buckets=7, num_sdf_blocks=64, streaming_extents=ext, streaming_dims=dims, streaming_min=minp)
+    scene = E.CUDASceneRepHashSDF(hp, T.make_scene_options(offline=False, gc=False, streaming_out_parts=1))
+    ray = E.CUDARayCastSDF(rp)
+    grid = E.CUDASceneRepChunkGrid(scene, ext, dims, minp, LIST, True, 1)  # worker thread running
+    voxel = hp.m_virtualVoxelSize
+    cand = [(x, y, z) for x in range(-5, 6) for y in range(-5, 6) for z in range(-5, 6)]
+    same = [p for p in cand if bucket_of(p, 7) == 3 and chunk_of(p, voxel, ext, minp, dims) == chunk_of((0, 0, 0), voxel, ext, minp, dims)][:14]
+    assert len(same) == 14
+    pos = np.array(same, dtype=np.int32)
+    vox = make_blocks(rng, len(pos))
+    path = str(tmp_path / "crowded.hashgrid")
+    maxp = tuple(m + d for m, d in zip(minp, dims))
+    write_file(path, voxel, {chunk_of((0, 0, 0), voxel, ext, minp, dims): (pos, vox)}, ext=ext, dims=dims, minp=minp, maxp=maxp)
+    grid.loadFromFile(path, np.array([100.0, 0.0, 0.0], np.float32), 1.0)  # (a sphere far away: nothing comes in yet)
+    assert grid.getStatistics()["blocks"] == 14
+    # frames that see nothing (no depth): alloc adds no block, the table holds what streaming brings
+    W, H = cp.m_imageWidth, cp.m_imageHeight
+    frame = E.DepthFrame(cp, depth=np.full((H, W), -np.inf, np.float32), color=np.full((H, W, 4), -np.inf, np.float32))
+    n = 12
+
+    def pose_at(x):
+        m = np.eye(4, dtype=np.float32)
+        m[0, 3] = x
+        return m.reshape(16)
+
+    poses = [pose_at(100.0)] + [pose_at(0.01 * k) for k in range(1, n)]  # the first sphere holds no chunk, the others the crowded one
+    recon = E.Reconstruction(scene, ray, grid, cp, E.Reconstruction.defaultOptions(s_streamingEnabled=1, s_streamingPos=(0.0, 0.0, 0.0), s_streamingRadius=10.0,
+                                                                                  s_allocAhead=1, s_maxFramesInFlight=4))
+    seq = E.Reconstruction.makeFrames(poses, [frame.depth_ptr] * n, [frame.color_ptr] * n)
+    recon.run(seq)
+    recon.synchronize()
+    st = recon.getStats()
+    assert st["frames"] == n and st["streamingFramesPipelined"] == n - 1, st
+    assert grid.getNumFailedInserts() > 0, "the pipelined pass was meant to overflow one bucket twice"
+    assert grid.getStatistics()["blocks"] == 0, "every block must have come in by now"
+    assert st["blocksStreamedIn"] == 14 and st["blocksStreamedOut"] == 0, st
+    s = scene.state()  # invariants: no block both free and used, none lost, free ones zero
+    order = canonical.lexsort_pos(pos)
+    assert np.array_equal(s["positions"], pos[order])
+    assert s["voxels"].tobytes() == np.ascontiguousarray(vox[order]).tobytes()
+    assert s["heap_free"] == 64 - 14
+    assert scene.debugHash()["duplicates"] == 0
+    grid.debugCheckForDuplicates()
+    recon.close()
+    grid.close()
