@@ -27,4 +27,6 @@ timeout -k 10 300 python3 bench.py --config cfg3 --no-streaming $B > $O/bench_cf
 timeout -k 10 300 python3 bench.py --config cfg3 --streaming-radius 1.2 --streaming-pos-z 1.6 --streaming-extent 0.5 $B > $O/bench_cfg3_streaming_traffic.json 2> $O/bench_cfg3_streaming_traffic.err
 timeout -k 10 300 python3 bench.py --config cfg4 $B > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 timeout -k 10 300 python3 bench.py --config cfg3 --scene S2 --no-streaming $B > $O/bench_dense_s2.json 2> $O/bench_dense_s2.err
-ls $O | head -50
+timeout -k 10 300 python3 bench.py --config cfg3 --streaming-radius 1.2 --streaming-pos-z 1.6 --streaming-extent 0.5 --steps 300 --warmup 100 $B > $O/bench_cfg3_streaming_traffic_300.json 2> $O/bench_cfg3_streaming_traffic_300.err
+timeout -k 10 200 python3 tools/valu_issue_probe.py --out $O/valu_issue.json > $O/valu_issue.log 2>&1
+ls $O | head -60

@@ -78,6 +78,26 @@ def main():
                 print(f"| {k} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} | {p.get('FETCH_SIZE', '')} | {p.get('WRITE_SIZE', '')} | "
                       f"{p.get('l2_hit_rate', '')} | {p.get('SQ_INSTS_VALU', '')} | {p.get('SQ_ACTIVE_INST_VALU', '')} |")
         traffic[what] = {r["kernel"]: r.get("hbm_bytes_2xFETCH_plus_WRITE") for r in rows if r.get("hbm_bytes_2xFETCH_plus_WRITE")}
+    # rocprofv3's stats average every launch of the process (the untimed pre-roll on the orbit's first frames included); what
+    # bench.py times live is the timed region: the same kernels averaged over the last `steps` dispatches of the trace
+    try:
+        line = json.loads([l for l in open(os.path.join(run, "bench_under_profiler.json")) if l.startswith("{")][-1])
+        steps = int(line["steps"])
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(os.path.join(run, "trace", "p_kernel_trace.csv"))):
+            per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        with open(os.path.join(prof, f"{tag}_bench_kernel_stats_timed_region.csv"), "w") as o:
+            o.write("kernel,launches_in_trace,avg_ns_all,avg_ns_last_%d_launches\n" % steps)
+            print(f"\n### timed region (last {steps} launches of the trace)")
+            for k in sorted(per):
+                v = sorted(per[k])
+                if len(v) >= steps:
+                    d = [e - b for b, e in v]
+                    o.write(f"{k},{len(d)},{sum(d) / len(d):.0f},{sum(d[-steps:]) / steps:.0f}\n")
+                    print(f"{k}: all {sum(d) / len(d) / 1e3:.2f} us, timed region {sum(d[-steps:]) / steps / 1e3:.2f} us; live in that run: "
+                          f"{line['roofline']['avg_launch_us'] if k.startswith('k_render') else ''}")
+    except (OSError, KeyError, ValueError, IndexError) as e:
+        print("no timed-region table:", e)
     traffic["_note"] = (f"HBM bytes per launch from profiles/{tag}_*_pmc.csv: (2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                         "(gfx950 reports half of wide reads; gathers are uncalibrated, so this is an upper bound); separate --pmc passes.  bench.py does "
                         "not copy these numbers into its line: `traffic` there is null unless counters ran in that very run.")
