@@ -416,7 +416,7 @@ private:
     unsigned int m_plFrame;                         // frames the pipeline has run (slot = frame & 1)
     bool m_plOutThisFrame;                          // pipelineStreamOut() of the current frame launched a pass
     uint32_t m_plOutTag, m_plOutMost;
-    struct { bool pending; uint32_t tag; unsigned int nIn; } m_plInsert[2]; // per staging slot: an insert whose outcome has not been looked at
+    struct { bool pending; uint32_t tag; unsigned int nIn, chunkBit; } m_plInsert[2]; // per staging slot: an insert whose outcome has not been looked at
     std::atomic<unsigned long long> m_plBlocksOut, m_plBlocksIn;
     SDFBlockDesc* d_plOutDesc[2];      // pass 1 -> pass 2 (device)
     SDFBlockDesc* h_plOutDesc[2];      // mapped pinned: pass 2 writes the blocks it moves straight to the host

@@ -104,7 +104,7 @@ CUDASceneRepChunkGrid::CUDASceneRepChunkGrid(CUDASceneRepHashSDF* sceneRepHashSD
     m_plDecisionPos = { 0.0f, 0.0f, 0.0f };
     m_plDecisionRadius = 0.0f;
     m_plFrame = 0; m_plOutThisFrame = false; m_plOutTag = 0; m_plOutMost = 0;
-    for (int i = 0; i < 2; i++) { m_plInsert[i].pending = false; m_plInsert[i].tag = 0; m_plInsert[i].nIn = 0; h_plInMirror[i] = nullptr; hd_plInMirror[i] = nullptr; }
+    for (int i = 0; i < 2; i++) { m_plInsert[i].pending = false; m_plInsert[i].tag = 0; m_plInsert[i].nIn = 0; m_plInsert[i].chunkBit = 0xffffffffu; h_plInMirror[i] = nullptr; hd_plInMirror[i] = nullptr; }
     m_plBlocksOut = 0; m_plBlocksIn = 0; m_plTag = 0;
     for (int i = 0; i < 2; i++) {
         d_plOutDesc[i] = nullptr; h_plOutDesc[i] = nullptr; h_plOutBlocks[i] = nullptr; hd_plOutDesc[i] = nullptr; hd_plOutBlocks[i] = nullptr;
@@ -967,11 +967,16 @@ void CUDASceneRepChunkGrid::pipelineCheckInsert(int slot, bool block)
     } else if (nFailed != 0) {
         checkHip(hipStreamSynchronize((hipStream_t)m_sceneRepHashSDF->getStream()), "hipStreamSynchronize");
         takeBackFailedInserts(nFailed, heapCountPrev, h_plInDesc[slot], h_plInBlocks[slot], nIn);
-        // the blocks that went back set their chunk's bit in the host's copy; the device's copy had it cleared by the pass.
-        // (The device is idle and the worker has no job: the host's copy is complete.)
-        std::lock_guard<std::mutex> l(m_gridMutex);
-        checkHip(hipMemcpy(d_bitMask, m_bitMask.data(), sizeof(unsigned int) * m_bitMask.size(), hipMemcpyHostToDevice), "bit mask");
-        m_bitMaskDirty = false;
+        // The blocks that went back set their chunk's bit in the host's copy; the device's copy had it cleared by the pass: set
+        // there too.  (That one bit, not an upload of the host's copy: a stream-out pass enqueued since may have set bits on
+        // the device that the host will only learn of when its blocks arrive.  The device is idle: the stream was synchronised.)
+        const unsigned int bit = m_plInsert[slot].chunkBit;
+        if (bit != 0xffffffffu) {
+            unsigned int word = 0;
+            checkHip(hipMemcpy(&word, d_bitMask + (bit >> 5), sizeof(word), hipMemcpyDeviceToHost), "bit mask word");
+            word |= 1u << (bit & 31u);
+            checkHip(hipMemcpy(d_bitMask + (bit >> 5), &word, sizeof(word), hipMemcpyHostToDevice), "bit mask word");
+        }
     }
     m_plBlocksIn += nIn;
 }
@@ -1045,13 +1050,16 @@ void CUDASceneRepChunkGrid::pipelineStreamIn(const StreamDecision& d)
     const uint32_t tag = ++m_plTag ? m_plTag : ++m_plTag;
     check(vh_stream_in_device(&hd, &hp, d.nIn, d_plInDesc[d.slot], (const VhVoxel*)d_plInBlocks[d.slot], token, d_insertFailed, d_bitMask, d.chunkBit,
                               hd_plInMirror[d.slot], tag, m_sceneRepHashSDF->getStream()), "vh_stream_in_device");
-    m_plInsert[d.slot].pending = true; m_plInsert[d.slot].tag = tag; m_plInsert[d.slot].nIn = d.nIn;
+    m_plInsert[d.slot].pending = true; m_plInsert[d.slot].tag = tag; m_plInsert[d.slot].nIn = d.nIn; m_plInsert[d.slot].chunkBit = d.chunkBit;
 }
 
 void CUDASceneRepChunkGrid::pipelineAsk(bool haveNext, const vh::vec3f& nextPosCamera, float nextRadius)
 {
     pipelineStart();
     if (!haveNext && !m_plOutThisFrame) { m_plFrame++; return; } // nothing for the worker to do
+    // The worker will stage the next frame's chunk in the buffer an insert of two frames back was made from: if that insert
+    // failed, its repair needs the buffer as it is -- look at its outcome first (the device passed it most of a frame ago)
+    if (haveNext) pipelineCheckInsert((int)((m_plFrame + 1u) & 1u), true);
     {
         std::lock_guard<std::mutex> l(m_plMutex);
         m_plJob.haveOut = m_plOutThisFrame;

@@ -349,8 +349,13 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     }
 
     if (streaming && step == kPipelined) {
-        (void)m_chunkGrid->pipelineStreamOut(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, mostOut);
-        m_chunkGrid->pipelineStreamIn(choice);
+        try {
+            (void)m_chunkGrid->pipelineStreamOut(p, m_opt.s_streamingRadius, CUDASceneRepChunkGrid::s_useParts, mostOut);
+            m_chunkGrid->pipelineStreamIn(choice);
+        } catch (...) { // (the chunk that was to come in is still in the worker's staging buffer: it goes back into the grid with the next drain)
+            m_chunkGrid->pipelineReturn(choice, p, m_opt.s_streamingRadius);
+            throw;
+        }
         m_stats.streamingFramesPipelined++;
         if (quiet) m_stats.streamingStepsSkipped++;
     } else if (streaming) { // :881-900
