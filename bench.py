@@ -732,6 +732,8 @@ def main(argv=None):
             "per_rank_frames_per_s": list(PER_RANK),
             "host_enqueue_us_per_frame": round(host_enqueue_us, 3),
             "host_wait_us_per_frame": round(host_wait_us, 3),
+            # timed frames whose pass over the voxels rode in computeNormals' launch (two launches a frame instead of three)
+            "frames_in_two_launches": int(st1.get("framesInTwoLaunches", 0) - st0.get("framesInTwoLaunches", 0)),
             "roofline": roofline,
             "rooflines": rooflines,
         }

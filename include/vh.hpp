@@ -119,7 +119,7 @@ public:
     // gives up a job of integrateAhead() that will not be finished (the caller is unwinding): the scene accepts
     // integrate() / integrateAhead() again.  Blocks an alloc pass that already ran has added stay: they are empty, and
     // garbage collection takes them like any other unobserved block.
-    void abortAhead() { m_aheadPending = 0; }
+    void abortAhead();
     // frames whose pass over the voxels has started on the device (read from mapped host memory: no synchronisation)
     unsigned int getNumFramesStartedOnDevice() const;
     // whoever edits the table outside integrate() (streaming) says so: work prepared from the table before is void
@@ -159,6 +159,11 @@ private:
     int m_aheadPending;       // 0 none, 1 job prepared by integrateAhead()
     void* d_packedFrame;      // the frame as the alloc pass packs it for the pass over the voxels (8 bytes per pixel)
     size_t m_packedPixels;
+    uint32_t* d_riderDone;    // VH_RIDER_DONE_WORDS words (see VhFrameJob::d_riderDone)
+    uint32_t m_riderTotals[4]; // VhFrameJob::listDoneTotal, listClassTotal, splatDoneTotal, splatClassTotal as of the last launch
+    void keepRiderTotals();
+    unsigned int m_riderMostBlocks;
+    uint32_t fusedFlags() const;
     void prepareJob(const DepthCameraData&, const DepthCameraParams&, const unsigned int* d_bitMask);
 };
 

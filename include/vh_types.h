@@ -131,6 +131,7 @@ enum {
     VH_STATE_HEAP_UNDERFLOW = 0, /* consumeHeap found the heap empty */
     VH_STATE_INSERT_FAILED = 1,  /* stream-in: insertHashEntry returned false */
     VH_STATE_ALLOC_LOCK_LOST = 2,/* alloc requests that lost a bucket lock this pass */
+    VH_STATE_RIDER_GAVE_UP = 3,  /* workgroups of a co-launched pass over the voxels that gave up waiting for the launch's other riders (must stay 0) */
     VH_STATE_WORDS = 16
 };
 
@@ -226,7 +227,21 @@ typedef struct VhFrameJob {
     uint8_t allocLaunched, compactifyLaunched, pad0[2];
     uint32_t frameNumber; /* frames the scene had integrated when the job was made */
     uint32_t tableEpoch;  /* bumped by everything that edits the table outside integrate(): reset, streaming */
+    /* The frame's pass over the voxels (integrate + starve + GC, vh_integrate_fused) as a third rider of computeNormals' launch:
+     * its workgroups come last in the grid; they start when the launch's compactify workgroups have counted themselves off, and
+     * free no block before its splat workgroups have (vh_compute_normals_co2).  Prepared by integrateAhead(); integrateFinish()
+     * launches the pass itself if nobody did. */
+    uint32_t* d_riderDone;   /* VH_RIDER_DONE_WORDS words (the scene's): per stage its flags and counters */
+    uint32_t listDoneTotal, listClassTotal;   /* what the compactify stage's top counter / class counters read when every launch enqueued so far has finished (kept by the launcher) */
+    uint32_t splatDoneTotal, splatClassTotal; /* the same for the splat workgroups */
+    uint32_t fusedFlags;     /* VH_FUSED_* of the frame's pass */
+    int32_t fusedLockToken;
+    uint32_t* d_countMirror; /* the scene's mapped {block count, frame number} words, or NULL */
+    uint32_t mirrorTag;
+    uint8_t fusedPrepared, fusedLaunched, pad1[2];
 } VhFrameJob;
+#define VH_RIDER_DONE_COUNTERS 32 /* copies of a flag, 128 bytes apart */
+#define VH_RIDER_DONE_WORDS (2 * (2 * VH_RIDER_DONE_COUNTERS + 1) * 32) /* per stage ("list made", "table read"): flags, class counters, top counter */
 
 /* The switches reconstruction() reads (DSC/DepthSensing.cpp:720-924) when it runs headless over a recorded sequence at
  * given poses (s_binaryDumpSensorUseTrajectory = true, s_binaryDumpSensorUseTrajectoryOnlyInit = false), plus what is
@@ -272,9 +287,11 @@ typedef struct VhReconstructionStats {
     uint64_t failedInserts;      /* the voxel pool empty; stream-in inserts that found no slot (the blocks went back to the host grid) */
     uint64_t framesWithRiders;   /* frames whose alloc pass rode in the ray caster's launch and whose compactify pass rode in computeNormals' */
     uint64_t splatsMadeAheadUsed; /* ray casts that ran on an interval splat made ahead (inside the previous computeNormals launch): such a
-                                     frame is three launches -- k_render, k_compute_normals, k_integrate_fused */
+                                     frame is three launches -- k_render, k_compute_normals, k_integrate_fused -- or two (framesInTwoLaunches) */
     uint64_t streamingFramesPipelined; /* frames whose streaming step ran without a host wait (CUDASceneRepChunkGrid's pipeline: counts on the
                                           device, the chunk that comes in chosen a frame ahead); streamingStepsSkipped of them moved nothing */
+    uint64_t framesInTwoLaunches; /* frames whose pass over the voxels rode in computeNormals' launch too (VhFrameJob::fusedLaunched): k_render and
+                                     k_compute_normals are all the frame launches */
 } VhReconstructionStats;
 
 /* The GlobalAppState members (DSC/GlobalAppState.h:28-101) that the path reads, as filled from a zParameters*.txt

@@ -29,10 +29,17 @@ def main():
     st, en, kind = (raw[:, 0] - t0) / 100.0, (raw[:, 1] - t0) / 100.0, raw[:, 2]
     q = lambda a: [round(float(x), 2) for x in np.percentile(a, [0, 10, 50, 90, 100])]
     out = dict(groups=int(len(raw)))
-    for k, nm in ((1, "schedule"), (2, "splat"), (3, "compactify"), (4, "normals")):
+    for k, nm in ((1, "schedule"), (2, "splat"), (3, "compactify"), (4, "normals"), (6, "pass_wait"), (5, "pass")):
         m = kind == k
         if m.any():
             out[nm] = dict(n=int(m.sum()), start_us=q(st[m]), end_us=q(en[m]), life_us=q((en - st)[m]))
+    ph = lib.download(hd.d_hashCompactified + 16 * (ne // 2 + 8192), np.uint32, 4 * 2 * 512).reshape(512, 2, 4)
+    ph = ph[ph[:, 0, 3] == 0x5743]
+    if len(ph): # a compactify workgroup that kept something: bits + gather | slots | queue -> list atomic | boxes + stores | all stores out
+        t = np.stack([ph[:, 0, 0], ph[:, 0, 1], ph[:, 0, 2], ph[:, 1, 0], ph[:, 1, 1], ph[:, 1, 2]], axis=1).astype(np.int64)
+        d = np.diff(t, axis=1) / 100.0
+        out["compactify_phases_us"] = dict(n=int(len(ph)), kept=q(ph[:, 1, 3] & 0xffff), buckets=q(ph[:, 1, 3] >> 16),
+                                           gather=q(d[:, 0]), slots=q(d[:, 1]), atomic=q(d[:, 2]), boxes=q(d[:, 3]), drain=q(d[:, 4]))
     print(json.dumps(out))
 
 main()

@@ -317,9 +317,18 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
     m_tableEpoch = 0;
     d_packedFrame = nullptr;
     m_packedPixels = 0;
+    d_riderDone = nullptr;
+    std::memset(m_riderTotals, 0, sizeof(m_riderTotals));
+    // (scenes of more blocks in view than this keep the pass over the voxels in a launch of its own: there it is the frame's
+    // largest kernel and the launch is tuned for it.  0 switches the rider off.)
+    const char* riderMost = std::getenv("VH_INTEGRATE_RIDER_MAX_BLOCKS");
+    m_riderMostBlocks = riderMost ? (unsigned int)std::strtoul(riderMost, nullptr, 10) : 4096u;
     std::memset(&m_job, 0, sizeof(m_job));
     std::memset(&m_hashData, 0, sizeof(m_hashData));
     check(vh_hash_data_alloc(&m_hashData, &m_hashParams), "HashData::allocate");
+    // the counters the riders of computeNormals' launch count themselves off on (never reset: the totals are compared)
+    checkHip(hipMalloc((void**)&d_riderDone, VH_RIDER_DONE_WORDS * sizeof(uint32_t)), "rider counters");
+    checkHip(hipMemsetAsync(d_riderDone, 0, VH_RIDER_DONE_WORDS * sizeof(uint32_t), (hipStream_t)m_stream), "hipMemsetAsync");
     // mapped pinned word the fused integrate kernel mirrors the in-frustum block count into
     checkHip(hipHostMalloc((void**)&h_occupied, 2 * sizeof(uint32_t), hipHostMallocMapped), "hipHostMalloc");
     h_occupied[0] = h_occupied[1] = 0;
@@ -335,6 +344,7 @@ void CUDASceneRepHashSDF::destroy()
     delete m_timer;
     m_timer = nullptr;
     if (d_packedFrame) { (void)hipFree(d_packedFrame); d_packedFrame = nullptr; }
+    if (d_riderDone) { (void)hipFree(d_riderDone); d_riderDone = nullptr; }
     if (h_occupied) (void)hipHostFree(h_occupied);
     vh_hash_data_free(&m_hashData);
 }
@@ -450,6 +460,21 @@ void CUDASceneRepHashSDF::prepareJob(const DepthCameraData& cam, const DepthCame
     m_job.lockToken = nextLockToken();
     m_job.frameNumber = m_numIntegratedFrames;
     m_job.tableEpoch = m_tableEpoch;
+    m_job.d_riderDone = d_riderDone;
+    m_job.listDoneTotal = m_riderTotals[0]; m_job.listClassTotal = m_riderTotals[1];
+    m_job.splatDoneTotal = m_riderTotals[2]; m_job.splatClassTotal = m_riderTotals[3];
+}
+
+uint32_t CUDASceneRepHashSDF::fusedFlags() const
+{
+    uint32_t flags = 0;
+    if (m_options.s_garbageCollectionEnabled) {
+        flags |= VH_FUSED_GC;
+        if (m_numIntegratedFrames > 0 && m_options.s_garbageCollectionStarve != 0 &&
+            m_numIntegratedFrames % m_options.s_garbageCollectionStarve == 0)
+            flags |= VH_FUSED_STARVE;
+    }
+    return flags;
 }
 
 // DSC/CUDASceneRepHashSDF.h:64-83
@@ -472,13 +497,7 @@ void CUDASceneRepHashSDF::integrate(const vh::mat4f& lastRigidTransform, const D
 // integrate -> [starve] -> identify -> free in one pass over the voxels
 void CUDASceneRepHashSDF::integrateFused(const DepthCameraData& cam, const DepthCameraParams& cp)
 {
-    uint32_t flags = 0;
-    if (m_options.s_garbageCollectionEnabled) {
-        flags |= VH_FUSED_GC;
-        if (m_numIntegratedFrames > 0 && m_options.s_garbageCollectionStarve != 0 &&
-            m_numIntegratedFrames % m_options.s_garbageCollectionStarve == 0)
-            flags |= VH_FUSED_STARVE;
-    }
+    const uint32_t flags = fusedFlags();
     const bool timed = m_options.s_timingsDetailledEnabled;
     if (timed) m_timer->arm(ST_INTEGRATE); // (the kernel's own dispatch time stamps)
     // the packed frame is this frame's only if this frame's alloc pass wrote it (same image, same size)
@@ -500,7 +519,33 @@ VhFrameJob* CUDASceneRepHashSDF::integrateAhead(const vh::mat4f& lastRigidTransf
     m_aheadPending = 1;
     // offline mode loops over alloc with read-backs, the reference sequence reads the compactify count: not for a co-launch
     if (m_options.s_offlineProcessing || m_options.s_useReferenceLaunchSequence || m_options.s_timingsDetailledEnabled) return nullptr;
+    // the pass over the voxels may ride behind compactify in computeNormals' launch (vh_compute_normals_co2 decides)
+    pollOccupiedCount(false);
+    if (m_riderMostBlocks != 0u && m_hashParams.m_numOccupiedBlocks <= m_riderMostBlocks) {
+        m_job.fusedFlags = fusedFlags();
+        m_job.fusedLockToken = nextLockToken();
+        m_job.d_countMirror = (uint32_t*)m_occupiedEvent;
+        m_job.mirrorTag = m_numIntegratedFrames + 1u;
+        m_job.fusedPrepared = 1;
+    }
     return &m_job;
+}
+
+void CUDASceneRepHashSDF::keepRiderTotals()
+{
+    m_riderTotals[0] = m_job.listDoneTotal; m_riderTotals[1] = m_job.listClassTotal;
+    m_riderTotals[2] = m_job.splatDoneTotal; m_riderTotals[3] = m_job.splatClassTotal;
+}
+
+void CUDASceneRepHashSDF::abortAhead()
+{
+    if (m_aheadPending && m_job.fusedLaunched) { // (the frame's pass over the voxels is in the queue already: the frame counts)
+        keepRiderTotals();
+        m_counterCleared = false;
+        m_occupiedPending = true;
+        m_numIntegratedFrames++;
+    }
+    m_aheadPending = 0;
 }
 
 void CUDASceneRepHashSDF::integrateFinish(const DepthCameraData& cam, const DepthCameraParams& cp)
@@ -511,7 +556,10 @@ void CUDASceneRepHashSDF::integrateFinish(const DepthCameraData& cam, const Dept
     else alloc(cam, cp, m_job.d_bitMask, true);
     if (m_job.compactifyLaunched) m_counterCleared = false;
     else compactifyHashEntries(cp);
-    if (m_options.s_useReferenceLaunchSequence) {
+    keepRiderTotals();
+    if (m_job.fusedLaunched) {
+        m_occupiedPending = true; // (it rode in computeNormals' launch)
+    } else if (m_options.s_useReferenceLaunchSequence) {
         integrateDepthMap(cam, cp);
         garbageCollect(cp);
     } else {

@@ -285,67 +285,149 @@ VHD BlockBox block_box(const VhHashParams& hp, const VhDepthCameraParams& cp, in
 // the spare words of a compactified entry: {x0 | y0 << 16, w | h << 8 | flags << 16, tag}
 VHD uint4 pack_box(uint32_t offset, const BlockBox& b, uint32_t tag) { return make_uint4(offset, b.x0 | (b.y0 << 16), b.w | (b.h << 8) | (b.flags << 16), tag); }
 
-// One lane per word of 32 occupancy bits; what a workgroup keeps is queued in LDS and appended to the list with ONE
-// atomic per workgroup (agent-scope atomics on one address are served one after the other at the memory side of the
-// eight L2s, ~12 ns each: with one per wave and slot the dense scene's 8 700 blocks cost 40 us).  The queued entries
-// then get their boxes, one lane each.  Entries beyond the queue's capacity take the list directly.
+// A workgroup takes 256 words of 32 occupancy bits.  It first gathers its non-empty buckets (a lane per word), then reads
+// their slots a lane per slot, eight slots in flight per lane: the loads do not depend on each other, so the workgroup's life
+// is a few trips to memory -- with a lane per word and a loop over the word's bits it was one trip per set bit of the fullest
+// word of the wave, 5-6 us where the launch's other riders need 2 (and the pass over the voxels, when it rides in the same
+// launch, waits for the list).  What the workgroup keeps is queued in LDS and appended to the list with ONE atomic per
+// workgroup (agent-scope atomics on one address are served one after the other at the memory side of the eight L2s, ~12 ns
+// each: with one per wave and slot the dense scene's 8 700 blocks cost 40 us).  The queued entries then get their boxes, one
+// lane each.  Entries beyond the queue's capacity take the list directly.
 constexpr uint32_t kCompactQueue = 768;
 struct CompactShared {
     int4 q[kCompactQueue];
     uint32_t off[kCompactQueue];
-    uint32_t n, base;
+    uint32_t n, base, nBuckets;
+    uint16_t buckets[256 * 32]; // the non-empty buckets, relative to the workgroup's first
 };
+// An entry of the compactified list, written and read within ONE launch (the pass over the voxels as a rider of the launch
+// that makes its list, k_compute_normals): the L2s of the eight XCDs are not coherent with each other, so such an entry is
+// written through and read at the agent's coherence point (relaxed agent-scope atomics: the sc1 forms of the instructions)
+// instead of the writers writing their whole L2 back and the readers dropping theirs (a release / acquire pair at agent
+// scope costs exactly that, buffer_wbl2 / buffer_inv: measured, +30 us a frame).
+template <bool COHERENT> VHD void list_store(VhHashEntry* o, const int4 q, const uint4 box)
+{
+    if (COHERENT) {
+        uint64_t* const w = reinterpret_cast<uint64_t*>(o);
+        __hip_atomic_store(w + 0, (uint64_t)(uint32_t)q.x | ((uint64_t)(uint32_t)q.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + 1, (uint64_t)(uint32_t)q.z | ((uint64_t)(uint32_t)q.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + 2, (uint64_t)box.x | ((uint64_t)box.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + 3, (uint64_t)box.z | ((uint64_t)box.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *(reinterpret_cast<uint4*>(o) + 1) = box;
+        store_quad(o, q);
+    }
+}
+template <bool COHERENT> VHD int4 list_quad(const VhHashEntry* e)
+{
+    if (COHERENT) {
+        const uint64_t* const w = reinterpret_cast<const uint64_t*>(e);
+        const uint64_t a = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_int4((int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)(uint32_t)b, (int)(uint32_t)(b >> 32));
+    }
+    return load_quad(e);
+}
+template <bool COHERENT> VHD uint4 list_box(const VhHashEntry* e)
+{
+    if (COHERENT) {
+        const uint64_t* const w = reinterpret_cast<const uint64_t*>(e);
+        const uint64_t a = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+    return *(reinterpret_cast<const uint4*>(e) + 1);
+}
+
+template <bool COHERENT = false>
 __device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, uint32_t wordIdx, CompactShared& sh)
 {
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
     const uint32_t tag = frame_tag(hp, cp);
-    if (threadIdx.x == 0) sh.n = 0u;
+    const uint32_t lane = lane_id();
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42 // measurement build: the phases of a compactify workgroup (tools/riders_stamps.py)
+    uint32_t phase[6];
+    phase[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#define VH_COMPACT_PHASE(I) phase[I] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#define VH_COMPACT_PHASES_OUT { __syncthreads(); if (threadIdx.x == 0) { uint4* const at = reinterpret_cast<uint4*>(hd.d_hashCompactified) + (hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + 8192u + 2u * (wordIdx / 256u); \
+        at[0] = make_uint4(phase[0], phase[1], phase[2], 0x5743u); at[1] = make_uint4(phase[3], phase[4], (uint32_t)__builtin_amdgcn_s_memrealtime(), sh.n | (sh.nBuckets << 16)); } }
+#else
+#define VH_COMPACT_PHASE(I)
+#define VH_COMPACT_PHASES_OUT
+#endif
+    if (threadIdx.x == 0) { sh.n = 0u; sh.nBuckets = 0u; }
     __syncthreads();
+    // the non-empty buckets, gathered (their order does not matter)
     uint32_t bits = (wordIdx < nWords) ? hd.d_bucketBits[wordIdx] : 0u;
-    while (__any(bits != 0u)) {
-        const bool has = bits != 0u;
-        const uint32_t bit = has ? (uint32_t)(__ffs((int)bits) - 1) : 0u;
-        const uint32_t bucket = wordIdx * 32u + bit;
-        bits &= bits - 1u;
-        const VhHashEntry* e = &hd.d_hash[(uint64_t)bucket * VH_HASH_BUCKET_SIZE];
-        // the whole bucket in flight at once (10 x 32 B)
-        int4 qs[VH_HASH_BUCKET_SIZE];
-        uint32_t offs[VH_HASH_BUCKET_SIZE];
+    {
+        const uint32_t mine = (uint32_t)__popc(bits);
+        uint32_t incl = mine;
 #pragma unroll
-        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
+        for (uint32_t d = 1; d < kWave; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += t;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+        uint32_t at = 0;
+        if (lane == 0 && total != 0u) at = atomicAdd(&sh.nBuckets, total);
+        at = (uint32_t)__shfl((int)at, 0) + incl - mine;
+        while (bits != 0u) {
+            sh.buckets[at++] = (uint16_t)(threadIdx.x * 32u + (uint32_t)(__ffs((int)bits) - 1));
+            bits &= bits - 1u;
+        }
+    }
+    __syncthreads();
+    VH_COMPACT_PHASE(1)
+    const uint32_t nSlots = sh.nBuckets * VH_HASH_BUCKET_SIZE;
+    const uint64_t firstBucket = (uint64_t)(wordIdx - threadIdx.x) * 32u;
+    constexpr uint32_t kInFlight = 8;
+    for (uint32_t s0 = threadIdx.x; s0 < nSlots; s0 += 256u * kInFlight) { // (s0 < nSlots for all or none of a wave's lanes but in its last trip)
+        int4 qs[kInFlight];
+        uint32_t offs[kInFlight];
+#pragma unroll
+        for (uint32_t j = 0; j < kInFlight; j++) {
+            const uint32_t slot = s0 + 256u * j;
             qs[j] = make_int4(0, 0, 0, VH_FREE_ENTRY);
             offs[j] = 0;
-            if (has) { qs[j] = load_quad(&e[j]); offs[j] = e[j].offset; }
+            if (slot < nSlots) {
+                const VhHashEntry* e = &hd.d_hash[(firstBucket + sh.buckets[slot / VH_HASH_BUCKET_SIZE]) * VH_HASH_BUCKET_SIZE + slot % VH_HASH_BUCKET_SIZE];
+                qs[j] = load_quad(e);
+                offs[j] = e->offset;
+            }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < VH_HASH_BUCKET_SIZE; j++) {
+        for (uint32_t j = 0; j < kInFlight; j++) {
             const int4 q = qs[j];
-            const bool keep = has && q.w != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(q.x, q.y, q.z));
+            const bool keep = q.w != VH_FREE_ENTRY && block_in_frustum(hp, cp, mki3(q.x, q.y, q.z));
+            const uint64_t kept = __ballot(keep); // one LDS atomic per wave
+            if (kept == 0ull) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&sh.n, (uint32_t)__popcll(kept));
+            at = (uint32_t)__shfl((int)at, 0) + (uint32_t)__popcll(kept & lanemask_lt());
             if (keep) {
-                const uint32_t at = atomicAdd(&sh.n, 1u);
                 if (at < kCompactQueue) {
                     sh.q[at] = q;
                     sh.off[at] = offs[j];
                 } else { // the queue is full: straight to the list
                     VhHashEntry* o = &hd.d_hashCompactified[(uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, 1)];
-                    *(reinterpret_cast<uint4*>(o) + 1) = pack_box(offs[j], block_box(hp, cp, q.x, q.y, q.z), tag);
-                    store_quad(o, q);
+                    list_store<COHERENT>(o, q, pack_box(offs[j], block_box(hp, cp, q.x, q.y, q.z), tag));
                 }
             }
         }
     }
     __syncthreads();
+    VH_COMPACT_PHASE(2)
     const uint32_t n = min(sh.n, kCompactQueue);
     if (n == 0u) return; // (the same for every thread)
     if (threadIdx.x == 0) sh.base = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)n);
     __syncthreads();
+    VH_COMPACT_PHASE(3)
     const uint32_t base = sh.base;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const int4 q = sh.q[i];
         VhHashEntry* o = &hd.d_hashCompactified[base + i];
-        *(reinterpret_cast<uint4*>(o) + 1) = pack_box(sh.off[i], block_box(hp, cp, q.x, q.y, q.z), tag);
-        store_quad(o, q);
+        list_store<COHERENT>(o, q, pack_box(sh.off[i], block_box(hp, cp, q.x, q.y, q.z), tag));
     }
+    VH_COMPACT_PHASE(4)
+    VH_COMPACT_PHASES_OUT
 }
 
 __global__ __launch_bounds__(256) void k_compactify(VhHashData hd, VhHashParams hp, VhDepthCameraParams cp)
@@ -705,25 +787,56 @@ struct FusedArgs {
     uint32_t* countMirror;
     uint32_t mirrorTag;
     const uint2* packed;
+    const uint32_t* tableRead; // the pass as a rider (k_compute_normals): flags that read tableReadExpected once the launch's other
+    uint32_t tableReadExpected; // riders have read the table -- no block is freed before; NULL: nobody else reads it
 };
+// A rider waits for a flag another rider of the launch raises (rider_done): VH_RIDER_DONE_COUNTERS copies 128 bytes apart, set
+// to a number that only grows (compared modulo 2^32).  An exit every wave reaches: after ~1 s of polling the wait gives up
+// (never seen; the caller says so in the status words and the grid drains whatever happens).  Every lane of the wave calls it.
+VHD bool rider_wait(const uint32_t* flags, uint32_t expected)
+{
+    const uint32_t* const flag = flags + (blockIdx.x % VH_RIDER_DONE_COUNTERS) * 32u;
+    for (uint32_t polls = 0; polls < (1u << 22); polls++) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the same word for every lane: one request)
+        if ((int32_t)(v - expected) >= 0) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+template <uint32_t KERNARG_OFFSET> // where the kernel's argument block holds the FusedArgs (0: it is the kernel's only argument)
 VHD const FusedArgs* cold_args()
 {
     typedef const char __attribute__((address_space(4))) * KernargPtr;
-    KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr() + KERNARG_OFFSET;
     asm volatile("" : "+s"(p));
     return (const FusedArgs*)p;
 }
+template <uint32_t KERNARG_OFFSET>
 VHD bool free_block_cold(int ex, int ey, int ez, uint32_t lane) // every lane of the wave calls it
 {
-    const FusedArgs* a = cold_args();
+    const FusedArgs* a = cold_args<KERNARG_OFFSET>();
     const VhHashData hd = a->hd;
     const VhHashParams hp = a->hp;
+    if (KERNARG_OFFSET != 0u) { // a rider: the launch's splat workgroups read the table this edits
+        const uint32_t* const tableRead = a->tableRead;
+        if (tableRead && !rider_wait(tableRead, a->tableReadExpected) && lane == 0u) atomicAdd(&hd.d_state[VH_STATE_RIDER_GAVE_UP], 1u);
+    }
     return delete_hash_entry_element_wave(hd, hp, mki3(ex, ey, ez), a->lockToken, lane);
 }
 
+// the fused pass's shared memory (a kernel that carries the pass as a rider overlays it with its other riders')
 template <bool PACKED>
-__global__ __launch_bounds__(256)
-void k_integrate_fused(FusedArgs args)
+struct FusedShared {
+    float sMin[4];
+    uint32_t sMax[4];
+    int sFreed;
+    __attribute__((aligned(16))) uint2 sTile[PACKED ? 256 / kWave : 1][PACKED ? kIntegrateTileRows * kIntegrateTileStride : 2];
+};
+
+// The pass as a function of (workgroup index, number of workgroups): k_integrate_fused is a launch of its own, the fused
+// rider of k_compute_normals the last workgroups of that launch (below).
+template <bool PACKED, uint32_t KERNARG_OFFSET>
+VHD void integrate_fused_body(const FusedArgs& args, const uint32_t groupIdx, const uint32_t numGroups, FusedShared<PACKED>& sh)
 {
     const VhHashData& hd = args.hd;
     const VhHashParams& hp = args.hp;
@@ -733,34 +846,36 @@ void k_integrate_fused(FusedArgs args)
     uint32_t* const countMirror = args.countMirror;
     const uint32_t mirrorTag = args.mirrorTag;
     const uint2* const packed = args.packed;
-    __shared__ float sMin[4];
-    __shared__ uint32_t sMax[4];
-    __shared__ int sFreed;
-    __shared__ __attribute__((aligned(16))) uint2 sTile[PACKED ? 256 / kWave : 1][PACKED ? kIntegrateTileRows * kIntegrateTileStride : 2];
+    float (&sMin)[4] = sh.sMin;
+    uint32_t (&sMax)[4] = sh.sMax;
+    int& sFreed = sh.sFreed;
+    auto& sTile = sh.sTile;
     const uint32_t lane = lane_id();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const uint32_t nEntries = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
     // the count and the entry this workgroup / wave would start with in one trip (the list is Ne entries long: reading
     // beyond the count is reading stale entries, which are not used)
-    const uint32_t count = (uint32_t)hd.d_hashCompactifiedCounter[0];
+    constexpr bool COHERENT = KERNARG_OFFSET != 0u; // (a rider of the launch that makes the list: list_store)
+    const uint32_t count = COHERENT ? (uint32_t)__hip_atomic_load(hd.d_hashCompactifiedCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : (uint32_t)hd.d_hashCompactifiedCounter[0];
     // first block of this wave when waves take blocks: the active waves fill whole workgroups (the others leave at
     // once and free their slot: a workgroup's LDS and registers are held until its last wave is done)
-    const uint32_t wFirst = blockIdx.x * (256u / kWave) + wave;
+    const uint32_t wFirst = groupIdx * (256u / kWave) + wave;
     int4 qg = make_int4(0, 0, 0, 0), qw = make_int4(0, 0, 0, 0);
     uint4 boxw = make_uint4(0u, 0u, 0u, 0u); // the entry's second half: {offset, box, box, tag} (compactify_group)
-    if (blockIdx.x < nEntries) qg = load_quad(&hd.d_hashCompactified[blockIdx.x]);
+    if (groupIdx < nEntries) qg = list_quad<COHERENT>(&hd.d_hashCompactified[groupIdx]);
     if (wFirst < nEntries) {
-        qw = load_quad(&hd.d_hashCompactified[wFirst]);
-        if (PACKED) boxw = *(reinterpret_cast<const uint4*>(&hd.d_hashCompactified[wFirst]) + 1);
+        qw = list_quad<COHERENT>(&hd.d_hashCompactified[wFirst]);
+        if (PACKED) boxw = list_box<COHERENT>(&hd.d_hashCompactified[wFirst]);
     }
     // host-visible copy of the block count and the caller's tag (mapped pinned memory): replaces a per-frame
     // device->host copy, and lets the host see how far the device has come
-    if (countMirror && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint2*>(countMirror) = make_uint2(count, mirrorTag);
+    if (countMirror && groupIdx == 0 && threadIdx.x == 0) *reinterpret_cast<uint2*>(countMirror) = make_uint2(count, mirrorTag);
     const float thr = get_truncation(hp, cp.m_sensorDepthWorldMax);
 
-    if (count <= gridDim.x) {
+    if (count <= numGroups) {
         // ---- one workgroup per block
-        const uint32_t b = blockIdx.x;
+        const uint32_t b = groupIdx;
         if (b >= count) return;
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43 // measurement build: every workgroup's life in this shape, read by tools/integrate_stamps.py
         const uint32_t stampA = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -794,7 +909,7 @@ void k_integrate_fused(FusedArgs args)
             if (t == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
             if (decide) {
                 if (wave == 0u) {
-                    const bool f = free_block_cold(ex, ey, ez, lane);
+                    const bool f = free_block_cold<KERNARG_OFFSET>(ex, ey, ez, lane);
                     if (lane == 0u) sFreed = f ? 1 : 0;
                 }
                 __syncthreads();
@@ -816,7 +931,7 @@ void k_integrate_fused(FusedArgs args)
     // Measured and dropped: ceil(count / rounds) waves with `rounds` blocks each (SIMDs with five waves finished 3 us
     // after those with four: 27 us for 8 600 blocks), and a ticket counter (agent-scope atomics on one address are
     // served at the memory side of the eight L2s, ~12 ns each: 165 us).
-    const uint32_t nActive = min(min(count, kIntegrateWavesMost), gridDim.x * (256u / kWave));
+    const uint32_t nActive = min(min(count, kIntegrateWavesMost), numGroups * (256u / kWave));
     if (wFirst >= nActive) return;
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 9 // measurement build: shader clock over one wave's lifetime
     const uint64_t stampC0 = __builtin_amdgcn_s_memtime(), stampR0 = __builtin_amdgcn_s_memrealtime();
@@ -826,8 +941,8 @@ void k_integrate_fused(FusedArgs args)
     // this wave's place in the later rounds: the SIMD it sits on (unit g mod 256, wave of the workgroup) bit-reversed, then
     // the workgroup's turn on that unit -- a permutation of 0 .. 5119 whose every prefix is spread evenly over the SIMDs
     // (used as is when all 5 120 waves are active; with fewer waves, which happens below 5 120 blocks, there is one round)
-    const uint32_t simdOfMachine = ((blockIdx.x & 255u) << 2) | wave;
-    const uint32_t scattered = nActive == kIntegrateWavesMost ? (__brev(simdOfMachine) >> 22) + (blockIdx.x >> 8) * 1024u : wFirst;
+    const uint32_t simdOfMachine = ((groupIdx & 255u) << 2) | wave; // (as a rider the workgroups sit elsewhere: the order is then only a permutation)
+    const uint32_t scattered = nActive == kIntegrateWavesMost ? (__brev(simdOfMachine) >> 22) + (groupIdx >> 8) * 1024u : wFirst;
     int4 q = qw;
     uint4 qbox = boxw;
     uint2* tile = sTile[wave];
@@ -853,8 +968,8 @@ void k_integrate_fused(FusedArgs args)
         const uint32_t bNext = round * nActive + scattered;
         const bool hasNext = scattered < nActive && bNext < count;
         if (hasNext) { // its entry (both halves) behind this block's voxels
-            q = load_quad(&hd.d_hashCompactified[bNext]);
-            if (PACKED) qbox = *(reinterpret_cast<const uint4*>(&hd.d_hashCompactified[bNext]) + 1);
+            q = list_quad<COHERENT>(&hd.d_hashCompactified[bNext]);
+            if (PACKED) qbox = list_box<COHERENT>(&hd.d_hashCompactified[bNext]);
         }
         // (Requesting the next block's voxels here as well was measured: slower.  The waves do not wait for the stream --
         // the kernel is bound by instruction issue, ~1000 vector instructions per block at 4 cycles each.)
@@ -967,7 +1082,7 @@ void k_integrate_fused(FusedArgs args)
             const bool decide = (minSdf >= thr) || (maxW == 0u);
             if (lane == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
             // (the same decision in every lane: the reduction left every lane with the block's minimum and maximum)
-            if (__builtin_amdgcn_readfirstlane(decide ? 1 : 0) != 0) freed = free_block_cold(ex, ey, ez, lane);
+            if (__builtin_amdgcn_readfirstlane(decide ? 1 : 0) != 0) freed = free_block_cold<KERNARG_OFFSET>(ex, ey, ez, lane);
         }
         if (freed) {
 #pragma unroll
@@ -992,6 +1107,14 @@ void k_integrate_fused(FusedArgs args)
         reinterpret_cast<uint4*>(hd.d_hashCompactified)[nEntries / 2u + 3u * wFirst + 2u] = make_uint4(stamps[4], stamps[5], 0u, 0u);
     }
 #endif
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256)
+void k_integrate_fused(FusedArgs args)
+{
+    __shared__ FusedShared<PACKED> sh;
+    integrate_fused_body<PACKED, 0u>(args, blockIdx.x, gridDim.x, sh);
 }
 
 __global__ __launch_bounds__(256) void k_starve(VhHashData hd, VhHashParams hp)
@@ -2170,12 +2293,98 @@ struct CoSplat {
     uint32_t groups; // nSplatGroups (+ sched_groups() with a schedule); 0: nothing to co-launch
 };
 
-// computeNormalsDevice, DSC/CameraUtil.cu:669-697
-__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job, CoSplat splat)
+// The frame's pass over the voxels (integrate + starve + GC) as a third rider: the LAST workgroups of the launch, two launches
+// a frame instead of three.  The pass needs the compactified list, which this launch's compactify workgroups make, and it
+// frees blocks, which edits the table this launch's splat workgroups read.  So:
+//   * the compactify workgroups count themselves off when their part of the list is out (rider_done<0>), and a workgroup of
+//     the pass polls a flag until all have (rider_wait) before it reads the count or an entry;
+//   * the splat workgroups count themselves off when they have read the table (rider_done<1>), and a wave of the pass that
+//     is about to free a block (a handful per frame) waits for them first (free_block_cold); voxels it may touch at once.
+// A wait cannot be in vain: the hardware starts a launch's workgroups in grid order, so what a workgroup of the pass waits
+// for is running or done when it starts (and every wait gives up after ~1 s: VH_STATE_RIDER_GAVE_UP, never seen).
+// Between workgroups of ONE launch the eight XCDs' L2s are not coherent, and a release / acquire pair at agent scope is the
+// writer writing its whole L2 back and the reader dropping its own (buffer_wbl2 / buffer_inv per workgroup: measured, +30 us
+// a frame).  The list is the only data that crosses: it is written through and read at the coherence point (list_store), the
+// counters and flags are relaxed agent-scope atomics, and the writers wait for their stores before they count.
+// What it buys (cfg2, tools/riders_stamps.py): the list is complete ~6.5 us into the launch (a compactify workgroup is five
+// trips to memory, ~1 us each under load), the pass starts at ~8 and ends at ~13 us, where the launch alone ends at ~8.5 us and
+// a launch of the pass would then ramp up and take its own ~6.5: 1 us less per frame at 640x480, 3 us at 1080p.
+struct CoIntegrate {
+    FusedArgs args;
+    uint32_t* done;          // VH_RIDER_DONE_WORDS words, per stage: flags, class counters, top counter (rider_done; never reset)
+    uint32_t listExpected, listClassExpected;   // what the compactify stage's top counter / class counters read once this launch's workgroups are done: its flags are set to the first then
+    uint32_t splatExpected, splatClassExpected; // the same for the splat workgroups (flags: args.tableRead / tableReadExpected)
+    uint32_t first;          // the pass's first workgroup in the grid
+    uint32_t groups;         // 0: nothing to co-launch
+};
+struct NormalsKernargs { // (the argument block of k_compute_normals, for the offset of the pass's arguments in it)
+    float4* out; const float4* in; uint32_t width, height; CoCompactify job; CoSplat splat; CoIntegrate integ;
+};
+// A workgroup of stage STAGE (0: compactify, it has made its part of the list; 1: splat, it has read the table), the i-th of n,
+// counts itself off.  Counting on one word would not do: same-address atomics are served one after the other, ~12 ns each,
+// and a launch has up to 2 000 splat workgroups (measured: the launch twice as long).  So the workgroups count in
+// VH_RIDER_DONE_COUNTERS classes (i mod 32, a counter each, 128 bytes apart), the last of a class counts the class off on a
+// top counter, and the last class raises the flags.  Nothing is ever reset -- the host keeps what each word reads when all
+// launches so far are done -- so every class must grow by the same amount in every launch: n rounded up to a multiple of 32,
+// the workgroups whose i + 32 falls into the padding counting for two (the launcher sees to n >= 32).
+template <uint32_t STAGE>
+VHD void rider_done(const CoIntegrate& integ, const uint32_t i, const uint32_t n)
 {
-    __shared__ union RiderShared { SplatShared splat; CompactShared compact; } shared;
+    if (integ.groups == 0u) return;
+    // every thread's stores to the list have arrived (written through, list_store: waiting for them is all a release has to
+    // do here) and its loads from the table have returned
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+        uint32_t* const words = integ.done + STAGE * (2u * VH_RIDER_DONE_COUNTERS + 1u) * 32u; // flags, class counters, top counter
+        const uint32_t padded = (n + VH_RIDER_DONE_COUNTERS - 1u) / VH_RIDER_DONE_COUNTERS * VH_RIDER_DONE_COUNTERS;
+        const uint32_t add = (i + VH_RIDER_DONE_COUNTERS >= n && i + VH_RIDER_DONE_COUNTERS < padded) ? 2u : 1u;
+        const uint32_t classExpected = STAGE == 0u ? integ.listClassExpected : integ.splatClassExpected;
+        const uint32_t topExpected = STAGE == 0u ? integ.listExpected : integ.splatExpected;
+        uint32_t last = 0;
+        if (threadIdx.x == 0) {
+            const uint32_t before = __hip_atomic_fetch_add(&words[(VH_RIDER_DONE_COUNTERS + i % VH_RIDER_DONE_COUNTERS) * 32u], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + add == classExpected)
+                last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == topExpected ? 1u : 0u;
+        }
+        last = (uint32_t)__shfl((int)last, 0);
+        if (last && threadIdx.x < (uint32_t)VH_RIDER_DONE_COUNTERS)
+            __hip_atomic_store(&words[threadIdx.x * 32u], topExpected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// computeNormalsDevice, DSC/CameraUtil.cu:669-697
+__global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job, CoSplat splat, CoIntegrate integ)
+{
+    __shared__ union RiderShared { SplatShared splat; CompactShared compact; FusedShared<true> fused; } shared;
     SplatShared& sh = shared.splat;
     uint32_t g = blockIdx.x;
+    if (integ.groups != 0u && g >= integ.first) {
+        static_assert(VH_RIDER_DONE_COUNTERS <= kWave, "one lane per flag");
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
+        const uint32_t riderStamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        uint4* const riderStampAt = reinterpret_cast<uint4*>(job.hd.d_hashCompactified) + (job.hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + blockIdx.x;
+#endif
+        if (threadIdx.x < kWave) {
+            const bool ok = rider_wait(integ.done, integ.listExpected);
+            if (threadIdx.x == 0) shared.fused.sFreed = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (shared.fused.sFreed) { // (its share of the pass stays undone)
+            if (threadIdx.x == 0) atomicAdd(&integ.args.hd.d_state[VH_STATE_RIDER_GAVE_UP], 1u);
+            return;
+        }
+        __syncthreads(); // (sFreed is the pass's own from here)
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
+        if (threadIdx.x == 0) riderStampAt[integ.groups] = make_uint4(riderStamp0, (uint32_t)__builtin_amdgcn_s_memrealtime(), 6u, 0x5742u);
+#endif
+        integrate_fused_body<true, (uint32_t)(offsetof(NormalsKernargs, integ) + offsetof(CoIntegrate, args))>(integ.args, g - integ.first, integ.groups, shared.fused);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
+        __syncthreads();
+        if (threadIdx.x == 0) *riderStampAt = make_uint4(riderStamp0, (uint32_t)__builtin_amdgcn_s_memrealtime(), 5u, 0x5742u);
+#endif
+        return;
+    }
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42 // measurement build: every workgroup's life by kind, read by tools/riders_stamps.py
     const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
     uint4* const stampAt = reinterpret_cast<uint4*>(job.hd.d_hashCompactified) + (job.hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + blockIdx.x;
@@ -2183,31 +2392,37 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
 #else
 #define VH_GROUP_STAMP(KIND)
 #endif
-#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 31 // measurement builds: the riders of this launch, one at a time
-    if (g < splat.groups - splat.nSplatGroups) return; // no schedule workgroups
-#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 32
-    if (g < splat.groups) return; // no splat at all
-#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 33
-    if (g >= splat.groups && g - splat.groups < job.groups) return; // no compactify
-#elif defined(VH_KNOCKOUT) && VH_KNOCKOUT == 34
-    if (g >= splat.groups + job.groups) return; // no normals
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT >= 31 && VH_KNOCKOUT <= 34 // measurement builds: the riders of this launch, one at a time
+    {
+        const uint32_t nSchedK = splat.groups - splat.nSplatGroups;
+        const bool isSched = g < nSchedK, isCompact = !isSched && g - nSchedK < job.groups, isSplat = !isSched && !isCompact && g < splat.groups + job.groups;
+        if (VH_KNOCKOUT == 31 && isSched) return;               // no schedule workgroups
+        if (VH_KNOCKOUT == 32 && (isSched || isSplat)) return;  // no splat at all
+        if (VH_KNOCKOUT == 33 && isCompact) return;             // no compactify
+        if (VH_KNOCKOUT == 34 && !isSched && !isCompact && !isSplat) return; // no normals
+    }
 #endif
+    // the schedule workgroups first (the longest chains), then compactify (the pass over the voxels, if it rides, waits for
+    // its list), then the table's slices
+    const uint32_t nSched = splat.groups - splat.nSplatGroups;
+    if (g >= nSched && g - nSched < job.groups) {
+        g -= nSched;
+        if (integ.groups != 0u) compactify_group<true>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
+        else compactify_group<false>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
+        VH_GROUP_STAMP(3u)
+        rider_done<0u>(integ, g, job.groups);
+        return;
+    }
+    if (g >= nSched) g -= job.groups;
     if (g < splat.groups) {
-        // the schedule workgroups first (the longest chains), then the table's slices
-        const uint32_t nSched = splat.groups - splat.nSplatGroups;
         const uint32_t group = g < nSched ? splat.nSplatGroups + g : g - nSched;
         interval_splat_group(job.hd, job.hp, splat.cp, splat.rp, splat.heads, splat.lists, splat.cap, splat.sched, splat.phase, splat.numCUs,
                              splat.nSplatGroups, splat.feedback, group, sh);
         VH_GROUP_STAMP(group >= splat.nSplatGroups ? 1u : 2u)
+        rider_done<1u>(integ, g, splat.groups);
         return;
     }
     g -= splat.groups;
-    if (g < job.groups) {
-        compactify_group(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
-        VH_GROUP_STAMP(3u)
-        return;
-    }
-    g -= job.groups;
     const uint32_t idx = g * blockDim.x + threadIdx.x;
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
     if (job.groups != 0u && idx < width * height) {
@@ -3540,6 +3755,7 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
     args.hd = *hd; args.hp = *hp; args.cam = *cam; args.cp = *cp;
     args.flags = flags; args.lockToken = lockToken; args.countMirror = d_countMirror; args.mirrorTag = mirrorTag;
     args.packed = reinterpret_cast<const uint2*>(packed);
+    args.tableRead = nullptr; args.tableReadExpected = 0u;
     if (packed) VH_LAUNCH_TIMED(k_integrate_fused<true>, grid, 256, (hipStream_t)stream, args);
     else VH_LAUNCH_TIMED(k_integrate_fused<false>, grid, 256, (hipStream_t)stream, args);
     return vh_last_launch_error();
@@ -3707,7 +3923,40 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
             groups += sp.groups;
         }
     }
-    VH_LAUNCH_TIMED(k_compute_normals, groups, 256, (hipStream_t)stream, reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job, sp);
+    // the frame's pass over the voxels as a third rider (the last workgroups of the grid), if the scene has prepared it and its
+    // list is made in this very launch
+    CoIntegrate integ;
+    std::memset(&integ, 0, sizeof(integ));
+    if (fj && job.groups >= VH_RIDER_DONE_COUNTERS && (sp.groups == 0u || sp.groups >= VH_RIDER_DONE_COUNTERS) &&
+        fj->fusedPrepared && !fj->fusedLaunched && fj->d_riderDone && fj->d_packedFrame && fj->cam.d_depthData &&
+        fj->cp.m_imageWidth <= 0xffffu && fj->cp.m_imageHeight <= 0xffffu) {
+        integ.args.hd = fj->hashData; integ.args.hp = fj->hashParams; integ.args.cam = fj->cam; integ.args.cp = fj->cp;
+        integ.args.flags = fj->fusedFlags; integ.args.lockToken = fj->fusedLockToken;
+        integ.args.countMirror = fj->d_countMirror; integ.args.mirrorTag = fj->mirrorTag;
+        integ.args.packed = reinterpret_cast<const uint2*>(fj->d_packedFrame);
+        integ.done = fj->d_riderDone;
+        // (rider_done: a class of a stage grows by the stage's workgroups rounded up to 32s, over 32; the top counter by 32)
+        fj->listClassTotal += cdiv(job.groups, VH_RIDER_DONE_COUNTERS);
+        fj->listDoneTotal += VH_RIDER_DONE_COUNTERS;
+        integ.listExpected = fj->listDoneTotal;
+        integ.listClassExpected = fj->listClassTotal;
+        if (sp.groups != 0u) {
+            fj->splatClassTotal += cdiv(sp.groups, VH_RIDER_DONE_COUNTERS);
+            fj->splatDoneTotal += VH_RIDER_DONE_COUNTERS;
+        }
+        integ.splatExpected = fj->splatDoneTotal;
+        integ.splatClassExpected = fj->splatClassTotal;
+        if (sp.groups != 0u) {
+            integ.args.tableRead = fj->d_riderDone + (2u * VH_RIDER_DONE_COUNTERS + 1u) * 32u;
+            integ.args.tableReadExpected = integ.splatExpected;
+        }
+        integ.first = groups;
+        const uint32_t want = cdiv(fj->hashParams.m_numSDFBlocks, 4), most = device_num_cus() * 8u;
+        integ.groups = want < most ? want : most; // (as vh_integrate_fused)
+        groups += integ.groups;
+        fj->fusedLaunched = 1;
+    }
+    VH_LAUNCH_TIMED(k_compute_normals, groups, 256, (hipStream_t)stream, reinterpret_cast<float4*>(d_output4), reinterpret_cast<const float4*>(d_input4), width, height, job, sp, integ);
     return vh_last_launch_error();
 }
 

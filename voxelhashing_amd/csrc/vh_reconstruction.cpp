@@ -346,6 +346,7 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
         }
         m_stats.splatsMadeAheadUsed += m_rayCast->getNumSplatsMadeAheadUsed() - used0;
         if (job && job->allocLaunched && job->compactifyLaunched) m_stats.framesWithRiders++;
+        if (job && job->fusedLaunched) m_stats.framesInTwoLaunches++;
     }
 
     if (streaming && step == kPipelined) {

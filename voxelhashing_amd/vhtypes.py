@@ -20,6 +20,7 @@ STATE_WORDS = 16
 STATE_HEAP_UNDERFLOW = 0
 STATE_INSERT_FAILED = 1
 STATE_ALLOC_LOCK_LOST = 2
+STATE_RIDER_GAVE_UP = 3
 
 MINF = np.float32(-np.inf)
 
@@ -220,6 +221,18 @@ class FrameJob(C.Structure):
         ("pad0", C.c_uint8 * 2),
         ("frameNumber", C.c_uint32),
         ("tableEpoch", C.c_uint32),
+        ("d_riderDone", C.c_void_p),
+        ("listDoneTotal", C.c_uint32),
+        ("listClassTotal", C.c_uint32),
+        ("splatDoneTotal", C.c_uint32),
+        ("splatClassTotal", C.c_uint32),
+        ("fusedFlags", C.c_uint32),
+        ("fusedLockToken", C.c_int32),
+        ("d_countMirror", C.c_void_p),
+        ("mirrorTag", C.c_uint32),
+        ("fusedPrepared", C.c_uint8),
+        ("fusedLaunched", C.c_uint8),
+        ("pad1", C.c_uint8 * 2),
     ]
 
 
@@ -259,6 +272,7 @@ class ReconstructionStats(C.Structure):
         ("framesWithRiders", C.c_uint64),
         ("splatsMadeAheadUsed", C.c_uint64),
         ("streamingFramesPipelined", C.c_uint64),
+        ("framesInTwoLaunches", C.c_uint64),
     ]
 
 
