@@ -56,7 +56,7 @@ def online_is_deterministic(O, hp, cp, rp, poses, host, starve):
 def timed_path_against_oracle(E, O, vh, cfg, n, pose_step, starve, n_blocks, two_launches=True):
     """-> statistics of the frame-by-frame run.  The loop's options are bench.py's: online alloc, s_allocAhead = 1,
     s_maxFramesInFlight = 16, garbage collection on.  two_launches: the frame's pass over the voxels rides in
-    computeNormals' launch (the default for scenes of up to 4096 blocks in view), or has its own launch."""
+    computeNormals' launch (the default for scenes of up to 2048 blocks in view), or has its own launch."""
     c = dict(synth.CONFIGS[cfg])
     c.update(num_sdf_blocks=n_blocks)  # the table at full size; the voxel pool sized to be downloadable
     hp, cp, rp = synth.config_params(c)
@@ -92,9 +92,9 @@ def timed_path_against_oracle(E, O, vh, cfg, n, pose_step, starve, n_blocks, two
     # every ray cast but the first (three launches per frame)
     assert st["framesWithRiders"] == n - 1, st
     assert st["splatsMadeAheadUsed"] == n - 2, st
-    # (the pass rides when the scene's last known count of blocks in view is at most 4096: frame by frame that is the
+    # (the pass rides when the scene's last known count of blocks in view is at most 2048: frame by frame that is the
     # count of the frame before)
-    riding = sum(1 for k in range(1, n) if states[k - 1] <= 4096) if two_launches else 0
+    riding = sum(1 for k in range(1, n) if states[k - 1] <= 2048) if two_launches else 0
     assert st["framesInTwoLaunches"] == riding, (st, states)
     sw = scene.getState()
     assert sw[T.STATE_HEAP_UNDERFLOW] == 0 and sw[T.STATE_INSERT_FAILED] == 0 and sw[T.STATE_RIDER_GAVE_UP] == 0
@@ -112,7 +112,7 @@ def timed_path_against_oracle(E, O, vh, cfg, n, pose_step, starve, n_blocks, two
     canonical.assert_same_scene(scene.state(), final, f"{cfg}, {n} frames in one call")
     st1 = recon.getStats()
     assert st1["framesWithRiders"] == n - 1 and st1["splatsMadeAheadUsed"] == n - 2, st1
-    if not two_launches or max(states) <= 4096:
+    if not two_launches or max(states) <= 2048:
         assert st1["framesInTwoLaunches"] == riding, st1
     assert scene.getState()[T.STATE_RIDER_GAVE_UP] == 0
     ray.render(scene.getHashData(), scene.getHashParams(), cp, poses[-1])
@@ -131,7 +131,7 @@ def test_cfg2_native_loop_with_riders_at_the_timed_size(E, oracle_lib, vh):
 
 
 def test_cfg2_native_loop_with_the_pass_in_its_own_launch(E, oracle_lib, vh, monkeypatch):
-    """the same with three launches a frame (what scenes of more than 4096 blocks in view get): the scene reads the
+    """the same with three launches a frame (what scenes of more than 2048 blocks in view get): the scene reads the
     switch when it is made"""
     monkeypatch.setenv("VH_INTEGRATE_RIDER_MAX_BLOCKS", "0")
     r = timed_path_against_oracle(E, oracle_lib, vh, "cfg2", 6, 9, 3, 1 << 14, two_launches=False)

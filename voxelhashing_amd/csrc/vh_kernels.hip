@@ -251,27 +251,37 @@ VHD uint32_t frame_tag(const VhHashParams& hp, const VhDepthCameraParams& cp)
     for (int i = 0; i < 7; i++) t = (t ^ more[i]) * 0x01000193u + (t >> 15);
     return t | 1u; // never 0: a zeroed entry carries no box
 }
-VHD BlockBox block_box(const VhHashParams& hp, const VhDepthCameraParams& cp, int ex, int ey, int ez)
+struct BoxCorners { // what the eight corners add up to
+    int bx0, bx1, by0, by1;
+    float cz;
+    bool fine;
+};
+VHD BoxCorners box_no_corner()
 {
-    int bx0 = 0x7fffffff, bx1 = (int)0x80000000, by0 = 0x7fffffff, by1 = (int)0x80000000;
-    float cz = pinf();
-    bool fine = true;
-#pragma unroll
-    for (uint32_t c = 0; c < 8u; c++) {
-        const I3 pc = mki3(ex * VH_SDF_BLOCK_SIZE + ((c & 1u) ? 7 : 0), ey * VH_SDF_BLOCK_SIZE + ((c & 2u) ? 7 : 0), ez * VH_SDF_BLOCK_SIZE + ((c & 4u) ? 7 : 0));
-        const F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pc));
-        const float rz = __builtin_amdgcn_rcpf(pf.z);
-        const int cx = cvt_rz((pf.x * cp.fx * rz + cp.mx) + 0.5f), cy = cvt_rz((pf.y * cp.fy * rz + cp.my) + 0.5f); // (saturating; NaN -> 0)
-        bx0 = min(bx0, cx); bx1 = max(bx1, cx);
-        by0 = min(by0, cy); by1 = max(by1, cy);
-        cz = fminf(cz, pf.z);
-        fine = fine && pf.z >= 0x1p-20f && pf.z <= 0x1p20f && fabsf(pf.x * cp.fx) <= 0x1p60f && fabsf(pf.y * cp.fy) <= 0x1p60f;
-    }
-    const bool inFront = cz > 1e-3f;
+    BoxCorners a;
+    a.bx0 = 0x7fffffff; a.bx1 = (int)0x80000000; a.by0 = 0x7fffffff; a.by1 = (int)0x80000000;
+    a.cz = pinf();
+    a.fine = true;
+    return a;
+}
+VHD void box_add_corner(const VhHashParams& hp, const VhDepthCameraParams& cp, int ex, int ey, int ez, uint32_t c, BoxCorners& a)
+{
+    const I3 pc = mki3(ex * VH_SDF_BLOCK_SIZE + ((c & 1u) ? 7 : 0), ey * VH_SDF_BLOCK_SIZE + ((c & 2u) ? 7 : 0), ez * VH_SDF_BLOCK_SIZE + ((c & 4u) ? 7 : 0));
+    const F3 pf = mat_mul_p(hp.m_rigidTransformInverse, vvp_to_world(hp.m_virtualVoxelSize, pc));
+    const float rz = __builtin_amdgcn_rcpf(pf.z);
+    const int cx = cvt_rz((pf.x * cp.fx * rz + cp.mx) + 0.5f), cy = cvt_rz((pf.y * cp.fy * rz + cp.my) + 0.5f); // (saturating; NaN -> 0)
+    a.bx0 = min(a.bx0, cx); a.bx1 = max(a.bx1, cx);
+    a.by0 = min(a.by0, cy); a.by1 = max(a.by1, cy);
+    a.cz = fminf(a.cz, pf.z);
+    a.fine = a.fine && pf.z >= 0x1p-20f && pf.z <= 0x1p20f && fabsf(pf.x * cp.fx) <= 0x1p60f && fabsf(pf.y * cp.fy) <= 0x1p60f;
+}
+VHD BlockBox box_of_corners(const VhDepthCameraParams& cp, const BoxCorners& a)
+{
+    const bool inFront = a.cz > 1e-3f;
     // (coordinates beyond +-2^30 would overflow the arithmetic below: such a block is simply not staged)
-    const bool sane = bx0 > -(1 << 30) && bx1 < (1 << 30) && by0 > -(1 << 30) && by1 < (1 << 30);
-    const int x0i = max(bx0 - 1, 0) & ~1, x1i = min(bx1 + 1, (int)cp.m_imageWidth - 1);
-    const int y0i = max(by0 - 1, 0), y1i = min(by1 + 1, (int)cp.m_imageHeight - 1);
+    const bool sane = a.bx0 > -(1 << 30) && a.bx1 < (1 << 30) && a.by0 > -(1 << 30) && a.by1 < (1 << 30);
+    const int x0i = max(a.bx0 - 1, 0) & ~1, x1i = min(a.bx1 + 1, (int)cp.m_imageWidth - 1);
+    const int y0i = max(a.by0 - 1, 0), y1i = min(a.by1 + 1, (int)cp.m_imageHeight - 1);
     const bool staged = inFront && sane && x0i <= x1i && y0i <= y1i && (x1i - x0i) < (int)kIntegrateTile && (y1i - y0i) < (int)kIntegrateTileRows &&
                         (cp.m_imageWidth & 1u) == 0u && cp.m_imageWidth <= 0xffffu && cp.m_imageHeight <= 0xffffu;
     BlockBox b;
@@ -279,14 +289,37 @@ VHD BlockBox block_box(const VhHashParams& hp, const VhDepthCameraParams& cp, in
     b.y0 = staged ? (uint32_t)y0i : 0u;
     b.w = staged ? (uint32_t)(x1i - x0i + 1) : 0u;
     b.h = staged ? (uint32_t)(y1i - y0i + 1) : 0u;
-    b.flags = (staged ? VH_BOX_STAGED : 0u) | (fine ? VH_BOX_CERTIFIED : 0u);
+    b.flags = (staged ? VH_BOX_STAGED : 0u) | (a.fine ? VH_BOX_CERTIFIED : 0u);
     return b;
+}
+VHD BlockBox block_box(const VhHashParams& hp, const VhDepthCameraParams& cp, int ex, int ey, int ez)
+{
+    BoxCorners a = box_no_corner();
+#pragma unroll
+    for (uint32_t c = 0; c < 8u; c++) box_add_corner(hp, cp, ex, ey, ez, c, a);
+    return box_of_corners(cp, a);
+}
+// the same by eight neighbouring lanes, a corner each (every lane gets the box)
+VHD BlockBox block_box_by_eight_lanes(const VhHashParams& hp, const VhDepthCameraParams& cp, int ex, int ey, int ez)
+{
+    BoxCorners a = box_no_corner();
+    box_add_corner(hp, cp, ex, ey, ez, lane_id() & 7u, a);
+    int fine = a.fine ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        a.bx0 = min(a.bx0, __shfl_xor(a.bx0, o)); a.bx1 = max(a.bx1, __shfl_xor(a.bx1, o));
+        a.by0 = min(a.by0, __shfl_xor(a.by0, o)); a.by1 = max(a.by1, __shfl_xor(a.by1, o));
+        a.cz = fminf(a.cz, __shfl_xor(a.cz, o));
+        fine &= __shfl_xor(fine, o);
+    }
+    a.fine = fine != 0;
+    return box_of_corners(cp, a);
 }
 // the spare words of a compactified entry: {x0 | y0 << 16, w | h << 8 | flags << 16, tag}
 VHD uint4 pack_box(uint32_t offset, const BlockBox& b, uint32_t tag) { return make_uint4(offset, b.x0 | (b.y0 << 16), b.w | (b.h << 8) | (b.flags << 16), tag); }
 
 // A workgroup takes 256 words of 32 occupancy bits.  It first gathers its non-empty buckets (a lane per word), then reads
-// their slots a lane per slot, eight slots in flight per lane: the loads do not depend on each other, so the workgroup's life
+// their slots a lane per slot, four slots in flight per lane: the loads do not depend on each other, so the workgroup's life
 // is a few trips to memory -- with a lane per word and a loop over the word's bits it was one trip per set bit of the fullest
 // word of the wave, 5-6 us where the launch's other riders need 2 (and the pass over the voxels, when it rides in the same
 // launch, waits for the list).  What the workgroup keeps is queued in LDS and appended to the list with ONE atomic per
@@ -378,7 +411,7 @@ __device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, c
     VH_COMPACT_PHASE(1)
     const uint32_t nSlots = sh.nBuckets * VH_HASH_BUCKET_SIZE;
     const uint64_t firstBucket = (uint64_t)(wordIdx - threadIdx.x) * 32u;
-    constexpr uint32_t kInFlight = 8;
+    constexpr uint32_t kInFlight = 4; // (eight: 20 registers more for the launch's every wave, and no sooner done)
     for (uint32_t s0 = threadIdx.x; s0 < nSlots; s0 += 256u * kInFlight) { // (s0 < nSlots for all or none of a wave's lanes but in its last trip)
         int4 qs[kInFlight];
         uint32_t offs[kInFlight];
@@ -417,14 +450,35 @@ __device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, c
     VH_COMPACT_PHASE(2)
     const uint32_t n = min(sh.n, kCompactQueue);
     if (n == 0u) return; // (the same for every thread)
-    if (threadIdx.x == 0) sh.base = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)n);
+    // the workgroup's place in the list: asked for now, needed when the first boxes are done (a trip to memory)
+    uint32_t place = 0;
+    if (threadIdx.x == 0) place = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)n);
+    // the boxes, eight lanes per entry (a corner each: one lane per entry is ~300 instructions in a row, 1 us on a busy unit)
+    constexpr uint32_t kBoxRounds = 2; // (rounds of 32 entries whose boxes wait in registers for the place; more entries: after it)
+    uint4 boxes[kBoxRounds];
+    const uint32_t mine = threadIdx.x >> 3;
+#pragma unroll
+    for (uint32_t r = 0; r < kBoxRounds; r++) {
+        const uint32_t i = min(r * 32u + mine, n - 1u); // (whole groups of eight lanes compute or idle; an idle group repeats the last entry)
+        if (r * 32u < n) {
+            const int4 q = sh.q[i];
+            boxes[r] = pack_box(sh.off[i], block_box_by_eight_lanes(hp, cp, q.x, q.y, q.z), tag);
+        }
+    }
+    if (threadIdx.x == 0) sh.base = place;
     __syncthreads();
     VH_COMPACT_PHASE(3)
     const uint32_t base = sh.base;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int4 q = sh.q[i];
-        VhHashEntry* o = &hd.d_hashCompactified[base + i];
-        list_store<COHERENT>(o, q, pack_box(sh.off[i], block_box(hp, cp, q.x, q.y, q.z), tag));
+#pragma unroll
+    for (uint32_t r = 0; r < kBoxRounds; r++) {
+        const uint32_t i = r * 32u + mine;
+        if (i < n && (threadIdx.x & 7u) == 0u) list_store<COHERENT>(&hd.d_hashCompactified[base + i], sh.q[i], boxes[r]);
+    }
+    for (uint32_t r = kBoxRounds; r * 32u < n; r++) {
+        const uint32_t i = r * 32u + mine;
+        const int4 q = sh.q[min(i, n - 1u)];
+        const BlockBox b = block_box_by_eight_lanes(hp, cp, q.x, q.y, q.z);
+        if (i < n && (threadIdx.x & 7u) == 0u) list_store<COHERENT>(&hd.d_hashCompactified[base + i], q, pack_box(sh.off[i], b, tag));
     }
     VH_COMPACT_PHASE(4)
     VH_COMPACT_PHASES_OUT
@@ -2306,9 +2360,11 @@ struct CoSplat {
 // writer writing its whole L2 back and the reader dropping its own (buffer_wbl2 / buffer_inv per workgroup: measured, +30 us
 // a frame).  The list is the only data that crosses: it is written through and read at the coherence point (list_store), the
 // counters and flags are relaxed agent-scope atomics, and the writers wait for their stores before they count.
-// What it buys (cfg2, tools/riders_stamps.py): the list is complete ~6.5 us into the launch (a compactify workgroup is five
-// trips to memory, ~1 us each under load), the pass starts at ~8 and ends at ~13 us, where the launch alone ends at ~8.5 us and
-// a launch of the pass would then ramp up and take its own ~6.5: 1 us less per frame at 640x480, 3 us at 1080p.
+// What it buys (cfg2, tools/riders_stamps.py): the list is complete 5.9 us into the launch (a compactify workgroup is four or
+// five trips to memory, ~1 us each on a busy machine), the pass's workgroups see the flag at 6.8 us and are done at 11.8 us, where
+// the launch alone ends at ~8 us and a launch of the pass would then ramp up and take its own ~6 us: 2.4 us less per frame at
+// 640x480 (350 blocks in view), 3.3 us at 1080p (1200 blocks).  With more than 2048 blocks in view the pass deals blocks to
+// waves in an order made for a launch of its own; riding then costs 4 us a frame, and the scene keeps the separate launch.
 struct CoIntegrate {
     FusedArgs args;
     uint32_t* done;          // VH_RIDER_DONE_WORDS words, per stage: flags, class counters, top counter (rider_done; never reset)
@@ -2326,7 +2382,9 @@ struct NormalsKernargs { // (the argument block of k_compute_normals, for the of
 // VH_RIDER_DONE_COUNTERS classes (i mod 32, a counter each, 128 bytes apart), the last of a class counts the class off on a
 // top counter, and the last class raises the flags.  Nothing is ever reset -- the host keeps what each word reads when all
 // launches so far are done -- so every class must grow by the same amount in every launch: n rounded up to a multiple of 32,
-// the workgroups whose i + 32 falls into the padding counting for two (the launcher sees to n >= 32).
+// the workgroups whose i + 32 falls into the padding counting for two (n > 32 there).  A stage of few
+// workgroups counts on the top counter alone.
+constexpr uint32_t kRiderFewGroups = 128; // a stage of up to this many workgroups counts on one word (the launcher's totals follow: rider_totals)
 template <uint32_t STAGE>
 VHD void rider_done(const CoIntegrate& integ, const uint32_t i, const uint32_t n)
 {
@@ -2343,9 +2401,13 @@ VHD void rider_done(const CoIntegrate& integ, const uint32_t i, const uint32_t n
         const uint32_t topExpected = STAGE == 0u ? integ.listExpected : integ.splatExpected;
         uint32_t last = 0;
         if (threadIdx.x == 0) {
-            const uint32_t before = __hip_atomic_fetch_add(&words[(VH_RIDER_DONE_COUNTERS + i % VH_RIDER_DONE_COUNTERS) * 32u], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + add == classExpected)
+            if (n <= kRiderFewGroups) { // few enough to count on the top counter itself: a trip to memory less before the flags go up
                 last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == topExpected ? 1u : 0u;
+            } else {
+                const uint32_t before = __hip_atomic_fetch_add(&words[(VH_RIDER_DONE_COUNTERS + i % VH_RIDER_DONE_COUNTERS) * 32u], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + add == classExpected)
+                    last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == topExpected ? 1u : 0u;
+            }
         }
         last = (uint32_t)__shfl((int)last, 0);
         if (last && threadIdx.x < (uint32_t)VH_RIDER_DONE_COUNTERS)
@@ -2360,7 +2422,7 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
     SplatShared& sh = shared.splat;
     uint32_t g = blockIdx.x;
     if (integ.groups != 0u && g >= integ.first) {
-        static_assert(VH_RIDER_DONE_COUNTERS <= kWave, "one lane per flag");
+        static_assert(kRiderFewGroups >= VH_RIDER_DONE_COUNTERS && VH_RIDER_DONE_COUNTERS <= kWave, "one lane per flag");
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
         const uint32_t riderStamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
         uint4* const riderStampAt = reinterpret_cast<uint4*>(job.hd.d_hashCompactified) + (job.hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + blockIdx.x;
@@ -3927,7 +3989,7 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
     // list is made in this very launch
     CoIntegrate integ;
     std::memset(&integ, 0, sizeof(integ));
-    if (fj && job.groups >= VH_RIDER_DONE_COUNTERS && (sp.groups == 0u || sp.groups >= VH_RIDER_DONE_COUNTERS) &&
+    if (fj && job.groups != 0u &&
         fj->fusedPrepared && !fj->fusedLaunched && fj->d_riderDone && fj->d_packedFrame && fj->cam.d_depthData &&
         fj->cp.m_imageWidth <= 0xffffu && fj->cp.m_imageHeight <= 0xffffu) {
         integ.args.hd = fj->hashData; integ.args.hp = fj->hashParams; integ.args.cam = fj->cam; integ.args.cp = fj->cp;
@@ -3935,12 +3997,19 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
         integ.args.countMirror = fj->d_countMirror; integ.args.mirrorTag = fj->mirrorTag;
         integ.args.packed = reinterpret_cast<const uint2*>(fj->d_packedFrame);
         integ.done = fj->d_riderDone;
-        // (rider_done: a class of a stage grows by the stage's workgroups rounded up to 32s, over 32; the top counter by 32)
-        fj->listClassTotal += cdiv(job.groups, VH_RIDER_DONE_COUNTERS);
-        fj->listDoneTotal += VH_RIDER_DONE_COUNTERS;
+        // (rider_done: a class of a stage grows by the stage's workgroups rounded up to 32s, over 32, and the top counter by 32;
+        // a stage of few workgroups counts on the top counter alone)
+        if (job.groups <= kRiderFewGroups) {
+            fj->listDoneTotal += job.groups;
+        } else {
+            fj->listClassTotal += cdiv(job.groups, VH_RIDER_DONE_COUNTERS);
+            fj->listDoneTotal += VH_RIDER_DONE_COUNTERS;
+        }
         integ.listExpected = fj->listDoneTotal;
         integ.listClassExpected = fj->listClassTotal;
-        if (sp.groups != 0u) {
+        if (sp.groups != 0u && sp.groups <= kRiderFewGroups) {
+            fj->splatDoneTotal += sp.groups;
+        } else if (sp.groups != 0u) {
             fj->splatClassTotal += cdiv(sp.groups, VH_RIDER_DONE_COUNTERS);
             fj->splatDoneTotal += VH_RIDER_DONE_COUNTERS;
         }
