@@ -160,7 +160,7 @@ private:
     void* d_packedFrame;      // the frame as the alloc pass packs it for the pass over the voxels (8 bytes per pixel)
     size_t m_packedPixels;
     uint32_t* d_riderDone;    // VH_RIDER_DONE_WORDS words (see VhFrameJob::d_riderDone)
-    uint32_t m_riderTotals[4]; // VhFrameJob::listDoneTotal, listClassTotal, splatDoneTotal, splatClassTotal as of the last launch
+    uint32_t m_riderTotals[2]; // VhFrameJob::listDoneTotal, listClassTotal as of the last launch
     void keepRiderTotals();
     unsigned int m_riderMostBlocks;
     uint32_t fusedFlags() const;

@@ -228,12 +228,11 @@ typedef struct VhFrameJob {
     uint32_t frameNumber; /* frames the scene had integrated when the job was made */
     uint32_t tableEpoch;  /* bumped by everything that edits the table outside integrate(): reset, streaming */
     /* The frame's pass over the voxels (integrate + starve + GC, vh_integrate_fused) as a third rider of computeNormals' launch:
-     * its workgroups come last in the grid; they start when the launch's compactify workgroups have counted themselves off, and
-     * free no block before its splat workgroups have (vh_compute_normals_co2).  Prepared by integrateAhead(); integrateFinish()
+     * its workgroups come last in the grid; they start when the launch's compactify workgroups have counted themselves off
+     * (vh_compute_normals_co2).  Prepared by integrateAhead(); integrateFinish()
      * launches the pass itself if nobody did. */
-    uint32_t* d_riderDone;   /* VH_RIDER_DONE_WORDS words (the scene's): per stage its flags and counters */
-    uint32_t listDoneTotal, listClassTotal;   /* what the compactify stage's top counter / class counters read when every launch enqueued so far has finished (kept by the launcher) */
-    uint32_t splatDoneTotal, splatClassTotal; /* the same for the splat workgroups */
+    uint32_t* d_riderDone;   /* VH_RIDER_DONE_WORDS words (the scene's): the flags and counters of the compactify workgroups */
+    uint32_t listDoneTotal, listClassTotal;   /* what their top counter / class counters read when every launch enqueued so far has finished (kept by the launcher) */
     uint32_t fusedFlags;     /* VH_FUSED_* of the frame's pass */
     int32_t fusedLockToken;
     uint32_t* d_countMirror; /* the scene's mapped {block count, frame number} words, or NULL */
@@ -241,7 +240,7 @@ typedef struct VhFrameJob {
     uint8_t fusedPrepared, fusedLaunched, pad1[2];
 } VhFrameJob;
 #define VH_RIDER_DONE_COUNTERS 32 /* copies of a flag, 128 bytes apart */
-#define VH_RIDER_DONE_WORDS (2 * (2 * VH_RIDER_DONE_COUNTERS + 1) * 32) /* per stage ("list made", "table read"): flags, class counters, top counter */
+#define VH_RIDER_DONE_WORDS ((2 * VH_RIDER_DONE_COUNTERS + 1) * 32) /* flags, class counters, top counter */
 
 /* The switches reconstruction() reads (DSC/DepthSensing.cpp:720-924) when it runs headless over a recorded sequence at
  * given poses (s_binaryDumpSensorUseTrajectory = true, s_binaryDumpSensorUseTrajectoryOnlyInit = false), plus what is

@@ -464,7 +464,6 @@ void CUDASceneRepHashSDF::prepareJob(const DepthCameraData& cam, const DepthCame
     m_job.tableEpoch = m_tableEpoch;
     m_job.d_riderDone = d_riderDone;
     m_job.listDoneTotal = m_riderTotals[0]; m_job.listClassTotal = m_riderTotals[1];
-    m_job.splatDoneTotal = m_riderTotals[2]; m_job.splatClassTotal = m_riderTotals[3];
 }
 
 uint32_t CUDASceneRepHashSDF::fusedFlags() const
@@ -536,7 +535,6 @@ VhFrameJob* CUDASceneRepHashSDF::integrateAhead(const vh::mat4f& lastRigidTransf
 void CUDASceneRepHashSDF::keepRiderTotals()
 {
     m_riderTotals[0] = m_job.listDoneTotal; m_riderTotals[1] = m_job.listClassTotal;
-    m_riderTotals[2] = m_job.splatDoneTotal; m_riderTotals[3] = m_job.splatClassTotal;
 }
 
 void CUDASceneRepHashSDF::abortAhead()

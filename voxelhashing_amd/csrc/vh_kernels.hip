@@ -841,8 +841,6 @@ struct FusedArgs {
     uint32_t* countMirror;
     uint32_t mirrorTag;
     const uint2* packed;
-    const uint32_t* tableRead; // the pass as a rider (k_compute_normals): flags that read tableReadExpected once the launch's other
-    uint32_t tableReadExpected; // riders have read the table -- no block is freed before; NULL: nobody else reads it
 };
 // A rider waits for a flag another rider of the launch raises (rider_done): VH_RIDER_DONE_COUNTERS copies 128 bytes apart, set
 // to a number that only grows (compared modulo 2^32).  An exit every wave reaches: after ~1 s of polling the wait gives up
@@ -871,10 +869,11 @@ VHD bool free_block_cold(int ex, int ey, int ez, uint32_t lane) // every lane of
     const FusedArgs* a = cold_args<KERNARG_OFFSET>();
     const VhHashData hd = a->hd;
     const VhHashParams hp = a->hp;
-    if (KERNARG_OFFSET != 0u) { // a rider: the launch's splat workgroups read the table this edits
-        const uint32_t* const tableRead = a->tableRead;
-        if (tableRead && !rider_wait(tableRead, a->tableReadExpected) && lane == 0u) atomicAdd(&hd.d_state[VH_STATE_RIDER_GAVE_UP], 1u);
-    }
+    // (As a rider of k_compute_normals the pass frees blocks while that launch's splat workgroups read the table.  That needs no
+    // order: the delete never moves an entry -- it overwrites the freed one with one 16-byte store, clears counters and unlinks --
+    // and the splat reads every slot once, so it lists every live block, and the freed one or not.  Either is what the splat made
+    // BEFORE the pass, in a launch of its own, always was for the ray cast that uses it: a freed block that is still listed
+    // has all-zero voxels by then (weight 0: no sample reads it), see CoSplat.)
     return delete_hash_entry_element_wave(hd, hp, mki3(ex, ey, ez), a->lockToken, lane);
 }
 
@@ -2349,11 +2348,12 @@ struct CoSplat {
 
 // The frame's pass over the voxels (integrate + starve + GC) as a third rider: the LAST workgroups of the launch, two launches
 // a frame instead of three.  The pass needs the compactified list, which this launch's compactify workgroups make, and it
-// frees blocks, which edits the table this launch's splat workgroups read.  So:
-//   * the compactify workgroups count themselves off when their part of the list is out (rider_done<0>), and a workgroup of
-//     the pass polls a flag until all have (rider_wait) before it reads the count or an entry;
-//   * the splat workgroups count themselves off when they have read the table (rider_done<1>), and a wave of the pass that
-//     is about to free a block (a handful per frame) waits for them first (free_block_cold); voxels it may touch at once.
+// frees blocks, which edits the table this launch's splat workgroups read.
+//   * The compactify workgroups count themselves off when their part of the list is out (rider_done), and a workgroup of the
+//     pass polls a flag until all have (rider_wait) before it reads the count or an entry.
+//   * The frees and the splat need no order (free_block_cold): the splat lists every live block whatever happens, and a freed
+//     one or not -- which is all the same to the ray cast it is made for.  (The first version had the splat workgroups count
+//     themselves off too and the frees wait for them: 0.4 us a frame for nothing.)
 // A wait cannot be in vain: the hardware starts a launch's workgroups in grid order, so what a workgroup of the pass waits
 // for is running or done when it starts (and every wait gives up after ~1 s: VH_STATE_RIDER_GAVE_UP, never seen).
 // Between workgroups of ONE launch the eight XCDs' L2s are not coherent, and a release / acquire pair at agent scope is the
@@ -2367,51 +2367,46 @@ struct CoSplat {
 // waves in an order made for a launch of its own; riding then costs 4 us a frame, and the scene keeps the separate launch.
 struct CoIntegrate {
     FusedArgs args;
-    uint32_t* done;          // VH_RIDER_DONE_WORDS words, per stage: flags, class counters, top counter (rider_done; never reset)
-    uint32_t listExpected, listClassExpected;   // what the compactify stage's top counter / class counters read once this launch's workgroups are done: its flags are set to the first then
-    uint32_t splatExpected, splatClassExpected; // the same for the splat workgroups (flags: args.tableRead / tableReadExpected)
+    uint32_t* done;          // VH_RIDER_DONE_WORDS words: flags, class counters, top counter (rider_done; never reset)
+    uint32_t listExpected, listClassExpected;   // what the compactify workgroups' top counter / class counters read once this launch's are done: the flags are set to the first then
     uint32_t first;          // the pass's first workgroup in the grid
     uint32_t groups;         // 0: nothing to co-launch
 };
 struct NormalsKernargs { // (the argument block of k_compute_normals, for the offset of the pass's arguments in it)
     float4* out; const float4* in; uint32_t width, height; CoCompactify job; CoSplat splat; CoIntegrate integ;
 };
-// A workgroup of stage STAGE (0: compactify, it has made its part of the list; 1: splat, it has read the table), the i-th of n,
-// counts itself off.  Counting on one word would not do: same-address atomics are served one after the other, ~12 ns each,
-// and a launch has up to 2 000 splat workgroups (measured: the launch twice as long).  So the workgroups count in
+// A compactify workgroup, the i-th of n, has made its part of the list and counts itself off.  Counting on one word would not do: same-address atomics are served one after the other, ~12 ns each,
+// and a launch has up to 1 000 of them (measured with the splat's 2 000 workgroups counting too: the launch twice as long).  So the workgroups count in
 // VH_RIDER_DONE_COUNTERS classes (i mod 32, a counter each, 128 bytes apart), the last of a class counts the class off on a
 // top counter, and the last class raises the flags.  Nothing is ever reset -- the host keeps what each word reads when all
 // launches so far are done -- so every class must grow by the same amount in every launch: n rounded up to a multiple of 32,
 // the workgroups whose i + 32 falls into the padding counting for two (n > 32 there).  A stage of few
 // workgroups counts on the top counter alone.
 constexpr uint32_t kRiderFewGroups = 128; // a stage of up to this many workgroups counts on one word (the launcher's totals follow: rider_totals)
-template <uint32_t STAGE>
 VHD void rider_done(const CoIntegrate& integ, const uint32_t i, const uint32_t n)
 {
     if (integ.groups == 0u) return;
     // every thread's stores to the list have arrived (written through, list_store: waiting for them is all a release has to
-    // do here) and its loads from the table have returned
+    // do here)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x < kWave) {
-        uint32_t* const words = integ.done + STAGE * (2u * VH_RIDER_DONE_COUNTERS + 1u) * 32u; // flags, class counters, top counter
+        uint32_t* const words = integ.done; // flags, class counters, top counter
         const uint32_t padded = (n + VH_RIDER_DONE_COUNTERS - 1u) / VH_RIDER_DONE_COUNTERS * VH_RIDER_DONE_COUNTERS;
         const uint32_t add = (i + VH_RIDER_DONE_COUNTERS >= n && i + VH_RIDER_DONE_COUNTERS < padded) ? 2u : 1u;
-        const uint32_t classExpected = STAGE == 0u ? integ.listClassExpected : integ.splatClassExpected;
-        const uint32_t topExpected = STAGE == 0u ? integ.listExpected : integ.splatExpected;
         uint32_t last = 0;
         if (threadIdx.x == 0) {
             if (n <= kRiderFewGroups) { // few enough to count on the top counter itself: a trip to memory less before the flags go up
-                last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == topExpected ? 1u : 0u;
+                last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == integ.listExpected ? 1u : 0u;
             } else {
                 const uint32_t before = __hip_atomic_fetch_add(&words[(VH_RIDER_DONE_COUNTERS + i % VH_RIDER_DONE_COUNTERS) * 32u], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + add == classExpected)
-                    last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == topExpected ? 1u : 0u;
+                if (before + add == integ.listClassExpected)
+                    last = __hip_atomic_fetch_add(&words[2u * VH_RIDER_DONE_COUNTERS * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == integ.listExpected ? 1u : 0u;
             }
         }
         last = (uint32_t)__shfl((int)last, 0);
         if (last && threadIdx.x < (uint32_t)VH_RIDER_DONE_COUNTERS)
-            __hip_atomic_store(&words[threadIdx.x * 32u], topExpected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&words[threadIdx.x * 32u], integ.listExpected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2472,7 +2467,7 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
         if (integ.groups != 0u) compactify_group<true>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
         else compactify_group<false>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
         VH_GROUP_STAMP(3u)
-        rider_done<0u>(integ, g, job.groups);
+        rider_done(integ, g, job.groups);
         return;
     }
     if (g >= nSched) g -= job.groups;
@@ -2481,7 +2476,6 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
         interval_splat_group(job.hd, job.hp, splat.cp, splat.rp, splat.heads, splat.lists, splat.cap, splat.sched, splat.phase, splat.numCUs,
                              splat.nSplatGroups, splat.feedback, group, sh);
         VH_GROUP_STAMP(group >= splat.nSplatGroups ? 1u : 2u)
-        rider_done<1u>(integ, g, splat.groups);
         return;
     }
     g -= splat.groups;
@@ -3817,7 +3811,6 @@ int vh_integrate_fused(const VhHashData* hd, const VhHashParams* hp, const VhDep
     args.hd = *hd; args.hp = *hp; args.cam = *cam; args.cp = *cp;
     args.flags = flags; args.lockToken = lockToken; args.countMirror = d_countMirror; args.mirrorTag = mirrorTag;
     args.packed = reinterpret_cast<const uint2*>(packed);
-    args.tableRead = nullptr; args.tableReadExpected = 0u;
     if (packed) VH_LAUNCH_TIMED(k_integrate_fused<true>, grid, 256, (hipStream_t)stream, args);
     else VH_LAUNCH_TIMED(k_integrate_fused<false>, grid, 256, (hipStream_t)stream, args);
     return vh_last_launch_error();
@@ -4007,18 +4000,6 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
         }
         integ.listExpected = fj->listDoneTotal;
         integ.listClassExpected = fj->listClassTotal;
-        if (sp.groups != 0u && sp.groups <= kRiderFewGroups) {
-            fj->splatDoneTotal += sp.groups;
-        } else if (sp.groups != 0u) {
-            fj->splatClassTotal += cdiv(sp.groups, VH_RIDER_DONE_COUNTERS);
-            fj->splatDoneTotal += VH_RIDER_DONE_COUNTERS;
-        }
-        integ.splatExpected = fj->splatDoneTotal;
-        integ.splatClassExpected = fj->splatClassTotal;
-        if (sp.groups != 0u) {
-            integ.args.tableRead = fj->d_riderDone + (2u * VH_RIDER_DONE_COUNTERS + 1u) * 32u;
-            integ.args.tableReadExpected = integ.splatExpected;
-        }
         integ.first = groups;
         const uint32_t want = cdiv(fj->hashParams.m_numSDFBlocks, 4), most = device_num_cus() * 8u;
         integ.groups = want < most ? want : most; // (as vh_integrate_fused)

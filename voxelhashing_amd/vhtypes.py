@@ -224,8 +224,6 @@ class FrameJob(C.Structure):
         ("d_riderDone", C.c_void_p),
         ("listDoneTotal", C.c_uint32),
         ("listClassTotal", C.c_uint32),
-        ("splatDoneTotal", C.c_uint32),
-        ("splatClassTotal", C.c_uint32),
         ("fusedFlags", C.c_uint32),
         ("fusedLockToken", C.c_int32),
         ("d_countMirror", C.c_void_p),
