@@ -249,8 +249,12 @@ VHD uint32_t frame_tag(const VhHashParams& hp, const VhDepthCameraParams& cp)
                                __float_as_uint(cp.my), cp.m_imageWidth, cp.m_imageHeight };
 #pragma unroll
     for (int i = 0; i < 7; i++) t = (t ^ more[i]) * 0x01000193u + (t >> 15);
-    return t | 1u; // never 0: a zeroed entry carries no box
+    return (t & 0x7fffffffu) | 1u; // never 0: a zeroed entry carries no box; bit 31 is the mark of a rider_tag
 }
+// The tag of a list made and read within ONE launch (the pass over the voxels as a rider): the frame's number.  The reader
+// takes an entry for this frame's when it carries this tag (CoIntegrate), so the tag must not repeat from one frame to the
+// next as frame_tag does when the camera stands still, and must not collide with one by chance.
+VHD uint32_t rider_tag(uint32_t frameNumber) { return 0x80000000u | frameNumber; }
 struct BoxCorners { // what the eight corners add up to
     int bx0, bx1, by0, by1;
     float cz;
@@ -345,6 +349,8 @@ template <bool COHERENT> VHD void list_store(VhHashEntry* o, const int4 q, const
         __hip_atomic_store(w + 0, (uint64_t)(uint32_t)q.x | ((uint64_t)(uint32_t)q.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(w + 1, (uint64_t)(uint32_t)q.z | ((uint64_t)(uint32_t)q.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(w + 2, (uint64_t)box.x | ((uint64_t)box.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the word with the tag goes last, when the others have arrived: a reader that finds the tag finds the entry
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(w + 3, (uint64_t)box.z | ((uint64_t)box.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         *(reinterpret_cast<uint4*>(o) + 1) = box;
@@ -371,10 +377,10 @@ template <bool COHERENT> VHD uint4 list_box(const VhHashEntry* e)
 }
 
 template <bool COHERENT = false>
-__device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, uint32_t wordIdx, CompactShared& sh)
+__device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, uint32_t wordIdx, CompactShared& sh, const uint32_t riderTag = 0u)
 {
     const uint32_t nWords = (hp.m_hashNumBuckets + 31) / 32;
-    const uint32_t tag = frame_tag(hp, cp);
+    const uint32_t tag = COHERENT ? riderTag : frame_tag(hp, cp);
     const uint32_t lane = lane_id();
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42 // measurement build: the phases of a compactify workgroup (tools/riders_stamps.py)
     uint32_t phase[6];
@@ -886,6 +892,64 @@ struct FusedShared {
     __attribute__((aligned(16))) uint2 sTile[PACKED ? 256 / kWave : 1][PACKED ? kIntegrateTileRows * kIntegrateTileStride : 2];
 };
 
+// One block by one workgroup, a voxel pair per thread: the pass's shape for up to 2048 blocks (integrate_fused_body), and the
+// pass as a rider of k_compute_normals (pass_rider_group).  q: the block's entry, b: its place in the list.
+template <bool PACKED, uint32_t KERNARG_OFFSET, class Shared> // Shared: a FusedShared (its sMin, sMax, sFreed)
+VHD void integrate_block_by_workgroup(const FusedArgs& args, Shared& sh, const int4 q, const uint32_t b, const float thr)
+{
+    const VhHashData& hd = args.hd;
+    const VhHashParams& hp = args.hp;
+    const uint32_t flags = args.flags;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43 // measurement build: every workgroup's life in this shape, read by tools/integrate_stamps.py
+    const uint32_t stampA = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t stampB = 0u, stampFreed = 0u;
+#endif
+    const uint32_t t = threadIdx.x;
+    const int ex = __builtin_amdgcn_readfirstlane(q.x), ey = __builtin_amdgcn_readfirstlane(q.y);
+    const int ez = __builtin_amdgcn_readfirstlane(q.z), ptr = __builtin_amdgcn_readfirstlane(q.w);
+    uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + t;
+    uint4 raw = *vp;
+    // voxel pair (2t, 2t+1): x = (2t)%8 (+1), y = (2t%64)/8, z = 2t/64
+    const I3 p0 = mki3(ex * VH_SDF_BLOCK_SIZE + (int)((2u * t) & 7u), ey * VH_SDF_BLOCK_SIZE + (int)(((2u * t) & 63u) >> 3), ez * VH_SDF_BLOCK_SIZE + (int)((2u * t) >> 6));
+    float minSdf = pinf();
+    uint32_t maxW = 0u;
+    integrate_pair<PACKED>(hp, args.cp, args.cam, args.packed, flags, p0, raw, minSdf, maxW);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
+    asm volatile("" : "+v"(raw.x));
+    stampB = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+    if (flags & VH_FUSED_GC) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            minSdf = fminf(minSdf, __shfl_xor(minSdf, o));
+            maxW = max(maxW, (uint32_t)__shfl_xor((int)maxW, o));
+        }
+        if (lane == 0) { sh.sMin[wave] = minSdf; sh.sMax[wave] = maxW; }
+        __syncthreads();
+        minSdf = fminf(fminf(sh.sMin[0], sh.sMin[1]), fminf(sh.sMin[2], sh.sMin[3]));
+        maxW = max(max(sh.sMax[0], sh.sMax[1]), max(sh.sMax[2], sh.sMax[3]));
+        const bool decide = (minSdf >= thr) || (maxW == 0u); // the same in every thread of the workgroup
+        if (t == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
+        if (decide) {
+            if (wave == 0u) {
+                const bool f = free_block_cold<KERNARG_OFFSET>(ex, ey, ez, lane);
+                if (lane == 0u) sh.sFreed = f ? 1 : 0;
+            }
+            __syncthreads();
+            if (sh.sFreed != 0) raw = make_uint4(0u, 0u, 0u, 0u);
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
+            stampFreed = 1u + (uint32_t)sh.sFreed;
+#endif
+        }
+    }
+    *vp = raw;
+#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
+    if (t == 0) reinterpret_cast<uint4*>(hd.d_hashCompactified)[(hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + b] = make_uint4(stampA, stampB, (uint32_t)__builtin_amdgcn_s_memrealtime(), 0x57430000u | stampFreed);
+#endif
+}
+
 // The pass as a function of (workgroup index, number of workgroups): k_integrate_fused is a launch of its own, the fused
 // rider of k_compute_normals the last workgroups of that launch (below).
 template <bool PACKED, uint32_t KERNARG_OFFSET>
@@ -928,54 +992,7 @@ VHD void integrate_fused_body(const FusedArgs& args, const uint32_t groupIdx, co
 
     if (count <= numGroups) {
         // ---- one workgroup per block
-        const uint32_t b = groupIdx;
-        if (b >= count) return;
-#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43 // measurement build: every workgroup's life in this shape, read by tools/integrate_stamps.py
-        const uint32_t stampA = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        uint32_t stampB = 0u, stampFreed = 0u;
-#endif
-        const uint32_t t = threadIdx.x;
-        const int ex = __builtin_amdgcn_readfirstlane(qg.x), ey = __builtin_amdgcn_readfirstlane(qg.y);
-        const int ez = __builtin_amdgcn_readfirstlane(qg.z), ptr = __builtin_amdgcn_readfirstlane(qg.w);
-        uint4* vp = reinterpret_cast<uint4*>(&hd.d_SDFBlocks[(uint32_t)ptr]) + t;
-        uint4 raw = *vp;
-        // voxel pair (2t, 2t+1): x = (2t)%8 (+1), y = (2t%64)/8, z = 2t/64
-        const I3 p0 = mki3(ex * VH_SDF_BLOCK_SIZE + (int)((2u * t) & 7u), ey * VH_SDF_BLOCK_SIZE + (int)(((2u * t) & 63u) >> 3), ez * VH_SDF_BLOCK_SIZE + (int)((2u * t) >> 6));
-        float minSdf = pinf();
-        uint32_t maxW = 0u;
-        integrate_pair<PACKED>(hp, cp, cam, packed, flags, p0, raw, minSdf, maxW);
-#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
-        asm volatile("" : "+v"(raw.x));
-        stampB = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-        if (flags & VH_FUSED_GC) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                minSdf = fminf(minSdf, __shfl_xor(minSdf, o));
-                maxW = max(maxW, (uint32_t)__shfl_xor((int)maxW, o));
-            }
-            if (lane == 0) { sMin[wave] = minSdf; sMax[wave] = maxW; }
-            __syncthreads();
-            minSdf = fminf(fminf(sMin[0], sMin[1]), fminf(sMin[2], sMin[3]));
-            maxW = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3]));
-            const bool decide = (minSdf >= thr) || (maxW == 0u); // the same in every thread of the workgroup
-            if (t == 0) hd.d_hashDecision[b] = decide ? 1 : 0;
-            if (decide) {
-                if (wave == 0u) {
-                    const bool f = free_block_cold<KERNARG_OFFSET>(ex, ey, ez, lane);
-                    if (lane == 0u) sFreed = f ? 1 : 0;
-                }
-                __syncthreads();
-                if (sFreed != 0) raw = make_uint4(0u, 0u, 0u, 0u);
-#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
-                stampFreed = 1u + (uint32_t)sFreed;
-#endif
-            }
-        }
-        *vp = raw;
-#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 43
-        if (t == 0) reinterpret_cast<uint4*>(hd.d_hashCompactified)[nEntries / 2u + b] = make_uint4(stampA, stampB, (uint32_t)__builtin_amdgcn_s_memrealtime(), 0x57430000u | stampFreed);
-#endif
+        if (groupIdx < count) integrate_block_by_workgroup<PACKED, KERNARG_OFFSET>(args, sh, qg, groupIdx, thr);
         return;
     }
 
@@ -2369,6 +2386,7 @@ struct CoIntegrate {
     FusedArgs args;
     uint32_t* done;          // VH_RIDER_DONE_WORDS words: flags, class counters, top counter (rider_done; never reset)
     uint32_t listExpected, listClassExpected;   // what the compactify workgroups' top counter / class counters read once this launch's are done: the flags are set to the first then
+    uint32_t riderTag;       // the tag of this launch's list entries (rider_tag)
     uint32_t first;          // the pass's first workgroup in the grid
     uint32_t groups;         // 0: nothing to co-launch
 };
@@ -2410,10 +2428,64 @@ VHD void rider_done(const CoIntegrate& integ, const uint32_t i, const uint32_t n
     }
 }
 
+// A workgroup of the pass as a rider: block `group` of the list, then (with more than `groups` blocks) group + groups, ...
+// It does not wait for the list to be complete before it starts: it polls ITS entry, which is there as soon as the compactify
+// workgroup that found the block has written it (the entry's tag says so: rider_tag, the last word list_store writes) -- on
+// average a microsecond before the slowest compactify workgroup is done, and without the trip for the count and the flag's own
+// way through memory (0.9 us).  The count it needs only afterwards: to know whether the list goes on beyond the launch's
+// workgroups, and, in workgroup 0, for the host's mirror.
+struct PassRiderShared {
+    FusedShared<false> fused;
+    int4 q;
+    uint32_t have, count;
+};
+template <uint32_t KERNARG_OFFSET>
+VHD void pass_rider_group(const CoIntegrate& integ, const uint32_t group, PassRiderShared& sh)
+{
+    const FusedArgs& args = integ.args;
+    const VhHashEntry* const list = args.hd.d_hashCompactified;
+    const uint32_t nEntries = args.hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
+    const float thr = get_truncation(args.hp, args.cp.m_sensorDepthWorldMax);
+    // 1. this workgroup's entry, or the end of the list (every lane of the wave reads the same words: one request each)
+    if (threadIdx.x < kWave) {
+        uint32_t have = 0u;
+        if (group < nEntries) {
+            const uint32_t* const flag = integ.done + (blockIdx.x % VH_RIDER_DONE_COUNTERS) * 32u;
+            for (uint32_t polls = 0; polls < (1u << 22); polls++) { // (an exit every wave reaches, as rider_wait)
+                if (list_box<true>(&list[group]).w == integ.riderTag) { have = 1u; break; }
+                if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - integ.listExpected) >= 0) break; // the list is complete (step 2 looks again)
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        int4 q = make_int4(0, 0, 0, 0);
+        if (have) q = list_quad<true>(&list[group]);
+        if (threadIdx.x == 0) { sh.q = q; sh.have = have; }
+    }
+    __syncthreads();
+    const bool early = sh.have != 0u;
+    if (early) integrate_block_by_workgroup<true, KERNARG_OFFSET>(args, sh.fused, sh.q, group, thr);
+    // 2. the whole list
+    if (threadIdx.x < kWave) {
+        uint32_t count = 0u;
+        if (rider_wait(integ.done, integ.listExpected)) count = (uint32_t)__hip_atomic_load(args.hd.d_hashCompactifiedCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (threadIdx.x == 0) atomicAdd(&args.hd.d_state[VH_STATE_RIDER_GAVE_UP], 1u); // (what is left of its share stays undone)
+        if (threadIdx.x == 0) sh.count = count;
+    }
+    __syncthreads();
+    const uint32_t count = sh.count;
+    // host-visible copy of the block count and the caller's tag (as integrate_fused_body)
+    if (args.countMirror && group == 0u && threadIdx.x == 0) *reinterpret_cast<uint2*>(args.countMirror) = make_uint2(count, args.mirrorTag);
+    for (uint32_t b = group; b < count; b += integ.groups) {
+        if (b == group && early) continue;
+        __syncthreads(); // (the previous block's reads of the shared words are done)
+        integrate_block_by_workgroup<true, KERNARG_OFFSET>(args, sh.fused, list_quad<true>(&list[b]), b, thr);
+    }
+}
+
 // computeNormalsDevice, DSC/CameraUtil.cu:669-697
 __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const float4* in, uint32_t width, uint32_t height, CoCompactify job, CoSplat splat, CoIntegrate integ)
 {
-    __shared__ union RiderShared { SplatShared splat; CompactShared compact; FusedShared<true> fused; } shared;
+    __shared__ union RiderShared { SplatShared splat; CompactShared compact; PassRiderShared pass; } shared;
     SplatShared& sh = shared.splat;
     uint32_t g = blockIdx.x;
     if (integ.groups != 0u && g >= integ.first) {
@@ -2422,20 +2494,7 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
         const uint32_t riderStamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
         uint4* const riderStampAt = reinterpret_cast<uint4*>(job.hd.d_hashCompactified) + (job.hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE) / 2u + blockIdx.x;
 #endif
-        if (threadIdx.x < kWave) {
-            const bool ok = rider_wait(integ.done, integ.listExpected);
-            if (threadIdx.x == 0) shared.fused.sFreed = ok ? 0 : 1;
-        }
-        __syncthreads();
-        if (shared.fused.sFreed) { // (its share of the pass stays undone)
-            if (threadIdx.x == 0) atomicAdd(&integ.args.hd.d_state[VH_STATE_RIDER_GAVE_UP], 1u);
-            return;
-        }
-        __syncthreads(); // (sFreed is the pass's own from here)
-#if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
-        if (threadIdx.x == 0) riderStampAt[integ.groups] = make_uint4(riderStamp0, (uint32_t)__builtin_amdgcn_s_memrealtime(), 6u, 0x5742u);
-#endif
-        integrate_fused_body<true, (uint32_t)(offsetof(NormalsKernargs, integ) + offsetof(CoIntegrate, args))>(integ.args, g - integ.first, integ.groups, shared.fused);
+        pass_rider_group<(uint32_t)(offsetof(NormalsKernargs, integ) + offsetof(CoIntegrate, args))>(integ, g - integ.first, shared.pass);
 #if defined(VH_KNOCKOUT) && VH_KNOCKOUT == 42
         __syncthreads();
         if (threadIdx.x == 0) *riderStampAt = make_uint4(riderStamp0, (uint32_t)__builtin_amdgcn_s_memrealtime(), 5u, 0x5742u);
@@ -2464,7 +2523,7 @@ __global__ __launch_bounds__(256) void k_compute_normals(float4* out, const floa
     const uint32_t nSched = splat.groups - splat.nSplatGroups;
     if (g >= nSched && g - nSched < job.groups) {
         g -= nSched;
-        if (integ.groups != 0u) compactify_group<true>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
+        if (integ.groups != 0u) compactify_group<true>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact, integ.riderTag);
         else compactify_group<false>(job.hd, job.hp, job.cp, g * blockDim.x + threadIdx.x, shared.compact);
         VH_GROUP_STAMP(3u)
         rider_done(integ, g, job.groups);
@@ -3990,6 +4049,7 @@ int vh_compute_normals_co2(float* d_output4, const float* d_input4, uint32_t wid
         integ.args.countMirror = fj->d_countMirror; integ.args.mirrorTag = fj->mirrorTag;
         integ.args.packed = reinterpret_cast<const uint2*>(fj->d_packedFrame);
         integ.done = fj->d_riderDone;
+        integ.riderTag = 0x80000000u | fj->mirrorTag; // (rider_tag of the frame's number)
         // (rider_done: a class of a stage grows by the stage's workgroups rounded up to 32s, over 32, and the top counter by 32;
         // a stage of few workgroups counts on the top counter alone)
         if (job.groups <= kRiderFewGroups) {
