@@ -459,6 +459,18 @@ __device__ void compactify_group(const VhHashData& hd, const VhHashParams& hp, c
     // the workgroup's place in the list: asked for now, needed when the first boxes are done (a trip to memory)
     uint32_t place = 0;
     if (threadIdx.x == 0) place = (uint32_t)atomicAdd(hd.d_hashCompactifiedCounter, (int)n);
+    if (COHERENT) {
+        // (the pass that reads this list in the same launch gives a workgroup to every block and never looks at a box: the
+        // entries go out as soon as the place is known, the tag in their last word)
+        if (threadIdx.x == 0) sh.base = place;
+        __syncthreads();
+        VH_COMPACT_PHASE(3)
+        const uint32_t base = sh.base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) list_store<true>(&hd.d_hashCompactified[base + i], sh.q[i], make_uint4(sh.off[i], 0u, 0u, tag));
+        VH_COMPACT_PHASE(4)
+        VH_COMPACT_PHASES_OUT
+        return;
+    }
     // the boxes, eight lanes per entry (a corner each: one lane per entry is ~300 instructions in a row, 1 us on a busy unit)
     constexpr uint32_t kBoxRounds = 2; // (rounds of 32 entries whose boxes wait in registers for the place; more entries: after it)
     uint4 boxes[kBoxRounds];
@@ -2451,10 +2463,14 @@ VHD void pass_rider_group(const CoIntegrate& integ, const uint32_t group, PassRi
         uint32_t have = 0u;
         if (group < nEntries) {
             const uint32_t* const flag = integ.done + (blockIdx.x % VH_RIDER_DONE_COUNTERS) * 32u;
+            const uint64_t* const tagWord = reinterpret_cast<const uint64_t*>(&list[group]) + 3;
             for (uint32_t polls = 0; polls < (1u << 22); polls++) { // (an exit every wave reaches, as rider_wait)
-                if (list_box<true>(&list[group]).w == integ.riderTag) { have = 1u; break; }
-                if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - integ.listExpected) >= 0) break; // the list is complete (step 2 looks again)
-                __builtin_amdgcn_s_sleep(4);
+                // both words in flight together: a poll is one trip to memory
+                const uint64_t w = __hip_atomic_load(tagWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(w >> 32) == integ.riderTag) { have = 1u; break; }
+                if ((int32_t)(f - integ.listExpected) >= 0) break; // the list is complete (step 2 looks again)
+                __builtin_amdgcn_s_sleep(2);
             }
         }
         int4 q = make_int4(0, 0, 0, 0);
