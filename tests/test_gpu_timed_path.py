@@ -1,8 +1,9 @@
 """The code path bench.py times, at the size it times, against the oracle.
 
 bench.py's headline number is the NATIVE frame loop (vh_reconstruction_run) with online alloc and the riders on:
-three launches per frame -- the alloc pass of frame k inside k_render's launch (ray cast of pose k-1), compactify and
-the next pose's interval splat inside k_compute_normals', then k_integrate_fused.  At 640x480 that k_render launch has a
+two launches per frame -- the alloc pass of frame k inside k_render's launch (ray cast of pose k-1); compactify, the
+next pose's interval splat and (up to 2048 blocks in view) the pass over the voxels inside k_compute_normals'; with
+more blocks k_integrate_fused is a third launch.  At 640x480 that k_render launch has a
 shape no small image reaches: all 4 800 tiles resident at six waves per SIMD, the dearest tiles split between two
 waves, the alloc rider filling the tail.  The tests here put the oracle (oracle/libvh_oracle.so, bit for bit: the
 canonical scene and all four ray-cast maps) behind exactly that path:
@@ -136,6 +137,41 @@ def test_cfg2_native_loop_with_the_pass_in_its_own_launch(E, oracle_lib, vh, mon
     monkeypatch.setenv("VH_INTEGRATE_RIDER_MAX_BLOCKS", "0")
     r = timed_path_against_oracle(E, oracle_lib, vh, "cfg2", 6, 9, 3, 1 << 14, two_launches=False)
     assert r["hits"] > 250000 and r["freed"] > 0, r
+
+
+def test_rider_and_own_launch_agree_over_a_long_run(E, vh, monkeypatch):
+    """150 frames of the cfg2 loop in ONE call, once with the pass over the voxels riding in computeNormals' launch (its
+    workgroups poll their list entries while the compactify workgroups are still writing others; blocks are freed while
+    the splat reads the table) and once with the pass in its own launch: the same scene and the same maps, bit for bit.
+    HIP against HIP -- the oracle is behind both paths in the tests above, for ten frames; this is about the many
+    interleavings of a long run."""
+    c = dict(synth.CONFIGS["cfg2"])
+    c.update(num_sdf_blocks=1 << 14)
+    hp, cp, rp = synth.config_params(c)
+    n = 150
+    poses = [shifted_pose(3 * k) for k in range(n)]
+    frames = [E.synth_frame(SHIFTED_S1, 0, p, cp) for p in poses]
+    opt = T.make_scene_options(offline=False, gc=True, starve=5)
+    seq = E.Reconstruction.makeFrames(poses, [f.depth_ptr for f in frames], [f.color_ptr for f in frames])
+    results = []
+    for most in ("2048", "0"):
+        monkeypatch.setenv("VH_INTEGRATE_RIDER_MAX_BLOCKS", most)
+        scene, ray = E.CUDASceneRepHashSDF(hp, opt), E.CUDARayCastSDF(rp)
+        recon = E.Reconstruction(scene, ray, None, cp, E.Reconstruction.defaultOptions(s_allocAhead=1, s_maxFramesInFlight=16))
+        recon.run(seq, 0, n)
+        recon.synchronize()
+        st = recon.getStats()
+        sw = scene.getState()
+        assert sw[T.STATE_RIDER_GAVE_UP] == 0 and sw[T.STATE_HEAP_UNDERFLOW] == 0, sw
+        results.append((scene.state(), ray.download(), st["framesInTwoLaunches"]))
+        recon.close()
+        ray.close()
+        scene.close()
+    (a, maps_a, two_a), (b, maps_b, two_b) = results
+    assert two_a == n - 1 and two_b == 0, (two_a, two_b)
+    assert a["num_occupied"] > 100
+    canonical.assert_same_scene(a, b, "rider against own launch, 150 frames")
+    assert_maps_equal(maps_a, maps_b, "rider against own launch: the last ray cast")
 
 
 @pytest.mark.slow
