@@ -319,10 +319,10 @@ void CUDASceneRepHashSDF::create(const HashParams& params)
     m_packedPixels = 0;
     d_riderDone = nullptr;
     std::memset(m_riderTotals, 0, sizeof(m_riderTotals));
-    // (scenes of more blocks in view than this keep the pass over the voxels in a launch of its own.  Up to 2048 blocks the pass
-    // gives a workgroup to every block and riding saves 2.4 us a frame at 350 blocks, 3.3 us at 1200; with more blocks it deals
-    // blocks to waves in an order made for a launch of its own, and riding COSTS 4 us a frame at 2500-4000 blocks (measured,
-    // DESIGN.md section 6).  0 switches the rider off.)
+    // (scenes of more blocks in view than this keep the pass over the voxels in a launch of its own.  Up to 2048 blocks the
+    // rider has a workgroup for every block and saves 4.8 us a frame at 350 blocks, 5 us at 1200; with more a workgroup takes
+    // several in turn, which costs 1.4 us a frame at 2500 - 5800 blocks and saves 2.3 at 8600 (measured).
+    // 0 switches the rider off.)
     const char* riderMost = std::getenv("VH_INTEGRATE_RIDER_MAX_BLOCKS");
     m_riderMostBlocks = riderMost ? (unsigned int)std::strtoul(riderMost, nullptr, 10) : 2048u;
     std::memset(&m_job, 0, sizeof(m_job));

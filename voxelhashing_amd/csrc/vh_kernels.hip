@@ -2378,8 +2378,12 @@ struct CoSplat {
 // The frame's pass over the voxels (integrate + starve + GC) as a third rider: the LAST workgroups of the launch, two launches
 // a frame instead of three.  The pass needs the compactified list, which this launch's compactify workgroups make, and it
 // frees blocks, which edits the table this launch's splat workgroups read.
-//   * The compactify workgroups count themselves off when their part of the list is out (rider_done), and a workgroup of the
-//     pass polls a flag until all have (rider_wait) before it reads the count or an entry.
+//   * A workgroup of the pass polls ITS entry of the list (pass_rider_group): the entry is there as soon as the compactify
+//     workgroup that found the block has written it, and its last word says so (rider_tag).  The compactify workgroups also
+//     count themselves off when their part of the list is out (rider_done), and the last one raises flags (rider_wait): that
+//     is how the pass learns that the list is complete -- for its length, which it needs afterwards -- and how a workgroup
+//     beyond the end of the list learns that it has nothing to do.  (The first version waited for the flags before it read
+//     anything: 1.4 us a frame more.)
 //   * The frees and the splat need no order (free_block_cold): the splat lists every live block whatever happens, and a freed
 //     one or not -- which is all the same to the ray cast it is made for.  (The first version had the splat workgroups count
 //     themselves off too and the frees wait for them: 0.4 us a frame for nothing.)
@@ -2389,11 +2393,12 @@ struct CoSplat {
 // writer writing its whole L2 back and the reader dropping its own (buffer_wbl2 / buffer_inv per workgroup: measured, +30 us
 // a frame).  The list is the only data that crosses: it is written through and read at the coherence point (list_store), the
 // counters and flags are relaxed agent-scope atomics, and the writers wait for their stores before they count.
-// What it buys (cfg2, tools/riders_stamps.py): the list is complete 5.9 us into the launch (a compactify workgroup is four or
-// five trips to memory, ~1 us each on a busy machine), the pass's workgroups see the flag at 6.8 us and are done at 11.8 us, where
-// the launch alone ends at ~8 us and a launch of the pass would then ramp up and take its own ~6 us: 2.4 us less per frame at
-// 640x480 (350 blocks in view), 3.3 us at 1080p (1200 blocks).  With more than 2048 blocks in view the pass deals blocks to
-// waves in an order made for a launch of its own; riding then costs 4 us a frame, and the scene keeps the separate launch.
+// What it buys (cfg2, tools/riders_stamps.py): the compactify workgroups are done 1.6 - 4.9 us into the launch (four trips to
+// memory each, ~1 us on a busy machine), the pass's workgroups 6.4 - 8.9 us, beside the splat's 8.1; the launch alone ended at
+// ~8 us and a launch of the pass would then ramp up and take its own ~6 us: 4.8 us less per frame at 640x480 (350 blocks in
+// view), 5 us at 1080p (1200 blocks).  With more blocks than the launch has workgroups for the pass (2048) a workgroup takes
+// several, one after the other: at 2500 - 5800 blocks (cfg3) that costs 1.4 us a frame more than it saves, at 8600 (the dense
+// scene) it saves 2.3 -- the scene keeps the pass in a launch of its own, whose wave-per-block shape is made for such lists.
 struct CoIntegrate {
     FusedArgs args;
     uint32_t* done;          // VH_RIDER_DONE_WORDS words: flags, class counters, top counter (rider_done; never reset)
@@ -2405,8 +2410,9 @@ struct CoIntegrate {
 struct NormalsKernargs { // (the argument block of k_compute_normals, for the offset of the pass's arguments in it)
     float4* out; const float4* in; uint32_t width, height; CoCompactify job; CoSplat splat; CoIntegrate integ;
 };
-// A compactify workgroup, the i-th of n, has made its part of the list and counts itself off.  Counting on one word would not do: same-address atomics are served one after the other, ~12 ns each,
-// and a launch has up to 1 000 of them (measured with the splat's 2 000 workgroups counting too: the launch twice as long).  So the workgroups count in
+// A compactify workgroup, the i-th of n, has made its part of the list and counts itself off.  Counting on one word would
+// not do: same-address atomics are served one after the other, ~12 ns each, and a launch has up to 1 000 of them (measured
+// with the splat's 2 000 workgroups counting too: the launch twice as long).  So the workgroups count in
 // VH_RIDER_DONE_COUNTERS classes (i mod 32, a counter each, 128 bytes apart), the last of a class counts the class off on a
 // top counter, and the last class raises the flags.  Nothing is ever reset -- the host keeps what each word reads when all
 // launches so far are done -- so every class must grow by the same amount in every launch: n rounded up to a multiple of 32,
