@@ -962,8 +962,8 @@ VHD void integrate_block_by_workgroup(const FusedArgs& args, Shared& sh, const i
 #endif
 }
 
-// The pass as a function of (workgroup index, number of workgroups): k_integrate_fused is a launch of its own, the fused
-// rider of k_compute_normals the last workgroups of that launch (below).
+// The pass in a launch of its own (k_integrate_fused), as a function of (workgroup index, number of workgroups).  As a rider of
+// k_compute_normals it is pass_rider_group (below), which shares the workgroup-per-block code above.
 template <bool PACKED, uint32_t KERNARG_OFFSET>
 VHD void integrate_fused_body(const FusedArgs& args, const uint32_t groupIdx, const uint32_t numGroups, FusedShared<PACKED>& sh)
 {
@@ -984,18 +984,16 @@ VHD void integrate_fused_body(const FusedArgs& args, const uint32_t groupIdx, co
     const uint32_t nEntries = hp.m_hashNumBuckets * VH_HASH_BUCKET_SIZE;
     // the count and the entry this workgroup / wave would start with in one trip (the list is Ne entries long: reading
     // beyond the count is reading stale entries, which are not used)
-    constexpr bool COHERENT = KERNARG_OFFSET != 0u; // (a rider of the launch that makes the list: list_store)
-    const uint32_t count = COHERENT ? (uint32_t)__hip_atomic_load(hd.d_hashCompactifiedCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : (uint32_t)hd.d_hashCompactifiedCounter[0];
+    const uint32_t count = (uint32_t)hd.d_hashCompactifiedCounter[0];
     // first block of this wave when waves take blocks: the active waves fill whole workgroups (the others leave at
     // once and free their slot: a workgroup's LDS and registers are held until its last wave is done)
     const uint32_t wFirst = groupIdx * (256u / kWave) + wave;
     int4 qg = make_int4(0, 0, 0, 0), qw = make_int4(0, 0, 0, 0);
     uint4 boxw = make_uint4(0u, 0u, 0u, 0u); // the entry's second half: {offset, box, box, tag} (compactify_group)
-    if (groupIdx < nEntries) qg = list_quad<COHERENT>(&hd.d_hashCompactified[groupIdx]);
+    if (groupIdx < nEntries) qg = load_quad(&hd.d_hashCompactified[groupIdx]);
     if (wFirst < nEntries) {
-        qw = list_quad<COHERENT>(&hd.d_hashCompactified[wFirst]);
-        if (PACKED) boxw = list_box<COHERENT>(&hd.d_hashCompactified[wFirst]);
+        qw = load_quad(&hd.d_hashCompactified[wFirst]);
+        if (PACKED) boxw = list_box<false>(&hd.d_hashCompactified[wFirst]);
     }
     // host-visible copy of the block count and the caller's tag (mapped pinned memory): replaces a per-frame
     // device->host copy, and lets the host see how far the device has come
@@ -1050,8 +1048,8 @@ VHD void integrate_fused_body(const FusedArgs& args, const uint32_t groupIdx, co
         const uint32_t bNext = round * nActive + scattered;
         const bool hasNext = scattered < nActive && bNext < count;
         if (hasNext) { // its entry (both halves) behind this block's voxels
-            q = list_quad<COHERENT>(&hd.d_hashCompactified[bNext]);
-            if (PACKED) qbox = list_box<COHERENT>(&hd.d_hashCompactified[bNext]);
+            q = load_quad(&hd.d_hashCompactified[bNext]);
+            if (PACKED) qbox = list_box<false>(&hd.d_hashCompactified[bNext]);
         }
         // (Requesting the next block's voxels here as well was measured: slower.  The waves do not wait for the stream --
         // the kernel is bound by instruction issue, ~1000 vector instructions per block at 4 cycles each.)
