@@ -2154,6 +2154,20 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     int* tab = tileTab[threadIdx.x / kWave];
     // consume the head and re-arm it, so that no separate clear pass is needed
     const uint4 head = heads[tile];
+    // With the large tables (three waves per SIMD: a trip to memory is not hidden by five other waves) the tile's list entries
+    // are asked for at once, whatever the head will say of their number -- the list's CAP places exist whether they are used or
+    // not: one trip instead of two before the table can be built (cfg3: 87.7 -> 84.6 us).  With the small tables the extra
+    // 3 MB at the start of the launch cost more than the trip (cfg2 +1.0 us, cfg4 +1.3): there the entries wait for the head.
+    constexpr uint32_t kPerLane = CAP / kWave; // list entries per lane
+    constexpr bool kListAhead = CAP > (uint32_t)VH_TILE_LIST_CAPACITY;
+    int4 ahead[kPerLane];
+    if (kListAhead) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPerLane; k++) {
+            ahead[k] = make_int4(0, 0, 0, VH_FREE_ENTRY);
+            if (lane + k * kWave < min(cap, CAP)) ahead[k] = lists[(size_t)tile * cap + lane + k * kWave];
+        }
+    }
     float tileZmin = __uint_as_float(head.x), tileZmax = __uint_as_float(head.y); // as splatted (lists == nullptr)
     if (lane == 0 && half == 0u) heads[tile] = make_uint4(0x7f800000u, 0u, 0u, 0u); // (a split tile: once both halves have read it)
     const uint32_t listed = min(head.z, min(cap, CAP));
@@ -2166,7 +2180,6 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     for (uint32_t i = lane; i < kTileTabSlots; i += kWave) tab[i * kTileSlotWords + 3u] = VH_FREE_ENTRY;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    constexpr uint32_t kPerLane = CAP / kWave; // list entries per lane
     int4 mine[kPerLane];
     uint32_t slot[kPerLane];
 #pragma unroll
@@ -2175,7 +2188,7 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
         mine[k] = make_int4(0, 0, 0, VH_FREE_ENTRY);
         slot[k] = 0u;
         if (i < listed) {
-            mine[k] = lists[(size_t)tile * cap + i];
+            mine[k] = kListAhead ? ahead[k] : lists[(size_t)tile * cap + i];
             uint32_t h = Lookup::slot_of(mine[k].x, mine[k].y, mine[k].z);
             // claim a slot through its pointer word, then fill in the position (nobody reads it before the barrier)
             while (atomicCAS(&tab[h * kTileSlotWords + 3u], VH_FREE_ENTRY, mine[k].w) != VH_FREE_ENTRY) h = (h + 1u) & (kTileTabSlots - 1u);
