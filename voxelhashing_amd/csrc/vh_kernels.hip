@@ -1788,6 +1788,52 @@ VHD bool trilinear(const VhHashData& hd, float vs, LK& lk, int p0in, const Taps&
     return true;
 }
 
+// trilinear<false> in two steps, for a march that asks for the NEXT sample's voxels before it blends this one's
+// (march_ray, PIPELINED): taps_issue resolves the eight pointers and puts the eight loads in flight (false: a block is
+// missing, the sample is invalid and nothing was asked for), taps_finish is the weight test and the blend.
+struct TapLoads {
+    uint2 r000, r100, r010, r001, r110, r011, r101, r111;
+};
+template <class LK>
+VHD bool taps_issue(const VhHashData& hd, LK& lk, int p0in, const Taps& tp, TapLoads& L)
+{
+    const uint32_t straddle = (tp.bxb != tp.bxa ? 1u : 0u) | (tp.byb != tp.bya ? 2u : 0u) | (tp.bzb != tp.bza ? 4u : 0u);
+    int p[8];
+    if (!lk.resolve(p0in, tp.bxa, tp.bya, tp.bza, tp.bxb, tp.byb, tp.bzb, straddle, p)) return false;
+    const int lx0 = tp.x0 & 7, ly0 = tp.y0 & 7, lz0 = tp.z0 & 7;
+    const int lx1 = tp.x1 & 7, ly1 = tp.y1 & 7, lz1 = tp.z1 & 7;
+    L.r000 = load_voxel(hd, p[0], lx0, ly0, lz0); L.r100 = load_voxel(hd, p[1], lx1, ly0, lz0);
+    L.r010 = load_voxel(hd, p[2], lx0, ly1, lz0); L.r001 = load_voxel(hd, p[4], lx0, ly0, lz1);
+    L.r110 = load_voxel(hd, p[3], lx1, ly1, lz0); L.r011 = load_voxel(hd, p[6], lx0, ly1, lz1);
+    L.r101 = load_voxel(hd, p[5], lx1, ly0, lz1); L.r111 = load_voxel(hd, p[7], lx1, ly1, lz1);
+    return true;
+}
+VHD bool taps_finish(TapLoads& L, float vs, float rvs, F3 pos, float& dist)
+{
+    // (all eight have arrived together: see trilinear)
+    asm volatile("" : "+v"(L.r000.x), "+v"(L.r000.y), "+v"(L.r100.x), "+v"(L.r100.y), "+v"(L.r010.x), "+v"(L.r010.y), "+v"(L.r001.x), "+v"(L.r001.y),
+                      "+v"(L.r110.x), "+v"(L.r110.y), "+v"(L.r011.x), "+v"(L.r011.y), "+v"(L.r101.x), "+v"(L.r101.y), "+v"(L.r111.x), "+v"(L.r111.y));
+    const Vox v000 = unpack_vox(L.r000), v100 = unpack_vox(L.r100), v010 = unpack_vox(L.r010), v001 = unpack_vox(L.r001);
+    const Vox v110 = unpack_vox(L.r110), v011 = unpack_vox(L.r011), v101 = unpack_vox(L.r101), v111 = unpack_vox(L.r111);
+    const uint32_t wmin = min(min(min(v000.cw, v100.cw), min(v010.cw, v001.cw)), min(min(v110.cw, v011.cw), min(v101.cw, v111.cw)));
+    if ((wmin >> 24) == 0u) return false;
+    const float fx = div_exact(pos.x, vs, rvs), fy = div_exact(pos.y, vs, rvs), fz = div_exact(pos.z, vs, rvs);
+    const float wx = fx - floorf(fx), wy = fy - floorf(fy), wz = fz - floorf(fz);
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    float d = 0.0f;
+    // (the reference's tap order and arithmetic: trilinear)
+    d += ((ux * uy) * uz) * v000.sdf;
+    d += ((wx * uy) * uz) * v100.sdf;
+    d += ((ux * wy) * uz) * v010.sdf;
+    d += ((ux * uy) * wz) * v001.sdf;
+    d += ((wx * wy) * uz) * v110.sdf;
+    d += ((ux * wy) * wz) * v011.sdf;
+    d += ((wx * uy) * wz) * v101.sdf;
+    d += ((wx * wy) * wz) * v111.sdf;
+    dist = d;
+    return true;
+}
+
 // The same function with the reference's tap-by-tap early-out, leaving the
 // partial sum in `dist` on failure: gradientForPoint (:174-195) ignores the
 // return value and uses that partial sum.
@@ -1883,7 +1929,7 @@ struct RayHit {
 // tile's conservative depth interval [tileZmin, tileZmax].  Written as march-until-sign-change / bisect / resume so
 // that the lanes of a wave run their bisections together instead of interleaving them with other lanes' marching;
 // each ray's own sequence of samples is the reference's.
-template <bool GRADIENTS, class LK>
+template <bool GRADIENTS, bool PIPELINED = false, class LK>
 VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const VhDepthCameraParams& cp, const VhRayCastParams& rp,
                    uint32_t x, uint32_t y, float tileZmin, float tileZmax, uint32_t half, float zMid, RayHit& out, uint32_t& cost
 #ifdef VH_RENDER_STATS
@@ -1946,6 +1992,99 @@ VHD void march_ray(LK& lk, const VhHashData& hd, const VhHashParams& hp, const V
                 rcur = nxt;
             }
         }
+    }
+
+    if constexpr (PIPELINED) {
+        // The same march with the NEXT sample's voxels asked for before this sample's are blended.  With three waves on a SIMD
+        // (the large tables) and, in a frame's long tail, one, a wave otherwise runs at the pace of its own chain: probe,
+        // eight loads, a trip to memory, blend, probe, ...  The next sample is the one the march would take next whatever this
+        // one turns out to be (also after a bisection that did not end the ray: the march resumes one increment on), so what
+        // is asked for early is never asked for in vain but at the end of the ray.  Every ray's sequence of samples, and what
+        // is computed from each, is the plain march's.
+        struct Pending {
+            float r;      // the sample's ray parameter
+            int skipped;  // samples without a block lay between the previous sample and this one
+            int state;    // 0: the ray has left the range, 1: the eight voxels are in flight, 2: a block is missing (invalid)
+            TapLoads L;
+        };
+        auto fetch = [&](float r0) -> Pending {
+            Pending f;
+            f.skipped = 0;
+            float r = r0;
+            Taps tp;
+            int p0 = kPtrUnknown;
+#pragma unroll 1
+            while (r < tStop) { // (A: samples whose first tap has no block)
+                cost += 1u;
+                tap_coords(rq, r, tp);
+                if (lk.first_tap(tp.bxa, tp.bya, tp.bza, p0)) break;
+                f.skipped = 1;
+                r += inc;
+            }
+            f.r = r;
+            f.state = 0;
+            if (r < tStop) {
+                cost += kCostSample;
+                f.state = taps_issue(hd, lk, p0, tp, f.L) ? 1 : 2;
+            }
+            return f;
+        };
+        Pending P = fetch(rcur);
+#pragma unroll 1
+        for (;;) {
+            bool candidate = false;
+            float dist = 0.0f;
+            Pending N;
+            N.state = 0; N.r = 0.0f; N.skipped = 0;
+#pragma unroll 1
+            for (;;) {
+                if (P.state == 0) break; // ray left the depth range (or the range in which blocks exist)
+                N = fetch(P.r + inc);
+                rcur = P.r;
+                lastValid = P.skipped ? 0 : lastValid;
+                bool ok = false;
+                if (P.state == 1) ok = taps_finish(P.L, rq.vs, rq.rvs, mk3(worldCamPos.x + rcur * worldDir.x, worldCamPos.y + rcur * worldDir.y, worldCamPos.z + rcur * worldDir.z), dist);
+                if (ok & (lastValid != 0) & (lastSdf > 0.0f) & (dist < 0.0f)) { candidate = true; break; }
+                lastSdf = ok ? dist : lastSdf;
+                lastAlpha = ok ? rcur : lastAlpha;
+                lastValid = ok ? 1 : 0;
+                P = N;
+            }
+            if (!candidate) break;
+            // ---- findIntersectionBisection :149-170 on [lastAlpha, rcur] (as below)
+            float a = lastAlpha, aDist = lastSdf, b = rcur, bDist = dist, c = 0.0f;
+            uint32_t color2 = 0u;
+            bool success = true;
+#pragma unroll 1
+            for (int i = 0; i < 3; i++) {
+                cost += kCostSample;
+                c = a + (aDist / (aDist - bDist)) * (b - a); // findIntersectionLinear :140-143
+                Taps ctp;
+                tap_coords(rq, c, ctp);
+                const F3 cpos = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
+                float cDist = 0.0f;
+                if (!trilinear<true>(hd, rq.vs, lk, kPtrUnknown, ctp, cpos, rq.rvs, cDist, color2)) { success = false; break; }
+                if (aDist * cDist > 0.0f) { a = c; aDist = cDist; }
+                else { b = c; bDist = cDist; }
+            }
+            if (success && fabsf(lastSdf - dist) < rp.m_thresSampleDist && fabsf(dist) < rp.m_thresDist) {
+                out.hit = true;
+                out.alpha = c;
+                out.color = color2;
+                if (GRADIENTS) {
+                    const F3 iso = mk3(worldCamPos.x + c * worldDir.x, worldCamPos.y + c * worldDir.y, worldCamPos.z + c * worldDir.z);
+                    const F3 g = gradient_for_point(hd, hp, iso);
+                    out.normal = mat_mul_d(rp.m_viewMatrix, mk3(-g.x, -g.y, -g.z));
+                }
+                break;
+            }
+            // no accepted hit: the (valid) march sample becomes the last sample and the march goes on (:248-252) -- at N
+            lastSdf = dist;
+            lastAlpha = rcur;
+            lastValid = 1;
+            P = N;
+        }
+        return;
     }
 
 #pragma unroll 1
@@ -2270,7 +2409,7 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     uint32_t cost = 0u;
     if (inImage && tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
         Lookup lk{ tab, complete, hd, hp };
-        march_ray<GRADIENTS>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, half, 0.5f * (tileZmin + tileZmax), out, cost VH_STAT_ARGS);
+        march_ray<GRADIENTS, (CAP > (uint32_t)VH_TILE_LIST_CAPACITY)>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, half, 0.5f * (tileZmin + tileZmax), out, cost VH_STAT_ARGS);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cost = max(cost, (uint32_t)__shfl_xor((int)cost, off));
