@@ -1917,6 +1917,10 @@ VHD void tap_coords(const RayQ& rq, float t, Taps& tp)
 }
 
 
+#ifndef VH_PIPELINE_SMALL // (measurement builds: the pipelined march with the small tables too)
+#define VH_PIPELINE_SMALL 0
+#endif
+
 struct RayHit {
     float alpha;    // ray parameter of the accepted intersection; NaN-free flag in `hit`
     uint32_t color; // packed colour of the last bisection sample
@@ -2409,7 +2413,7 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     uint32_t cost = 0u;
     if (inImage && tileZmin <= tileZmax) { // else: no allocated block can be read by this tile's rays, every sample is invalid
         Lookup lk{ tab, complete, hd, hp };
-        march_ray<GRADIENTS, (CAP > (uint32_t)VH_TILE_LIST_CAPACITY)>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, half, 0.5f * (tileZmin + tileZmax), out, cost VH_STAT_ARGS);
+        march_ray<GRADIENTS, (CAP > (uint32_t)VH_TILE_LIST_CAPACITY) || VH_PIPELINE_SMALL>(lk, hd, hp, cp, rp, x, y, tileZmin, tileZmax, half, 0.5f * (tileZmin + tileZmax), out, cost VH_STAT_ARGS);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cost = max(cost, (uint32_t)__shfl_xor((int)cost, off));
