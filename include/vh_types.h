@@ -281,7 +281,7 @@ typedef struct VhReconstructionStats {
                                     spans both copy streams) */
     uint64_t uploadsTimed;
     uint64_t uploadBytes;        /* bytes per frame upload */
-    uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to move nothing and that ran with three launches */
+    uint64_t streamingStepsSkipped; /* frames whose streaming step was known ahead to move nothing and that ran like a frame without streaming */
     uint64_t heapUnderflows;     /* the scene's status words as get_stats() found them (VH_STATE_*): alloc requests that found */
     uint64_t failedInserts;      /* the voxel pool empty; stream-in inserts that found no slot (the blocks went back to the host grid) */
     uint64_t framesWithRiders;   /* frames whose alloc pass rode in the ray caster's launch and whose compactify pass rode in computeNormals' */

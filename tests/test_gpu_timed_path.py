@@ -90,7 +90,7 @@ def timed_path_against_oracle(E, O, vh, cfg, n, pose_step, starve, n_blocks, two
     st = recon.getStats()
     assert st["frames"] == n and st["invalidFrames"] == 0
     # the launches really had the timed shape: riders in every frame that has a ray cast, the splat made ahead used by
-    # every ray cast but the first (three launches per frame)
+    # every ray cast but the first (two launches per frame, three with the pass in its own)
     assert st["framesWithRiders"] == n - 1, st
     assert st["splatsMadeAheadUsed"] == n - 2, st
     # (the pass rides when the scene's last known count of blocks in view is at most 2048: frame by frame that is the

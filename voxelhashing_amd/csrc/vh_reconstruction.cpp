@@ -9,7 +9,8 @@
 // What is not in the reference:
 //   * s_allocAhead: the pose of frame k is known before pose k-1 is ray-cast (it comes from the file), so the frame's
 //     alloc pass rides in the ray caster's launch (its last workgroups) and its compactify pass, with the next pose's
-//     interval splat, in computeNormals' (CUDASceneRepHashSDF::integrateAhead hands out the job): three launches per
+//     interval splat, in computeNormals' (CUDASceneRepHashSDF::integrateAhead hands out the job) -- and, up to 2048 blocks in view, the pass over the
+//     voxels there too: two launches, else three, per
 //     frame on ONE stream, no event.  With streaming on this happens in the frames whose streaming step is known a
 //     frame ahead to be a no-op (vh_stream_out_probe; frame() below);
 //   * s_framesOnHost: float depth + RGBX colour in host memory (what RGBDSensor::getDepthFloat / getColorRGBX hand
@@ -295,7 +296,7 @@ void Reconstruction::frame(const SequenceFrame& f, const SequenceFrame* next)
     //     THIS frame's sphere and part, behind the previous frame's alloc: nothing adds blocks between there and here);
     //   * the chunk that comes in was chosen and uploaded by the grid's worker while the device worked on the previous frame;
     //   * the counts stay on the device, the device keeps its own copy of the bit mask.
-    // A frame in which nothing leaves and nothing comes in is then three launches, like a frame without streaming (alloc
+    // A frame in which nothing leaves and nothing comes in is then two or three launches, like a frame without streaming (alloc
     // rides in the ray caster's launch, reading the device's bit mask); a frame with traffic is the reference's order of
     // launches, enqueued without waiting.  Without the answers (first frame, next pose unknown, a pass too large for the
     // pipeline's staging) the frame takes the reference's order of calls.
