@@ -153,6 +153,34 @@ def test_fine_voxels_switch_to_large_tile_tables(E, oracle_lib):
         assert_maps_equal(ray.download(), want, f"render {i}")
 
 
+@pytest.mark.parametrize("gradients", [False, True])
+def test_large_tile_tables_against_the_oracle(E, oracle_lib, gradients):
+    """the same scene as above against the ORACLE's render, without and with gradients: with the large tables the march asks
+    for the next sample's voxels before it blends this one's (march_ray, PIPELINED) -- every ray's samples, and what is made
+    of them, must still be the reference's"""
+    O = oracle_lib
+    hp = T.make_hash_params(1 << 16, 1 << 14, **synth.PARAM_SETS["P1"])
+    cp = T.make_depth_camera_params(320, 240)
+    rp = T.make_raycast_params(hp, cp, use_gradients=gradients)
+    opt = T.make_scene_options(offline=True, gc=False)
+    scene, ref = E.CUDASceneRepHashSDF(hp, opt), O.OracleScene(hp, cp, rp, opt)
+    frame = E.DepthFrame(cp)
+    poses = [synth.orbit_pose(k, n_frames=60) for k in range(3)]
+    for pose in poses:
+        E.synth_frame(synth.S1_SPHERES, 0, pose, cp, out=frame)
+        d, c = O.synth_frame(synth.S1_SPHERES, 0, pose, cp)
+        scene.integrate(pose, frame, cp, None)
+        ref.integrate(pose, d, c)
+    want = ref.render(poses[-1])
+    assert (want["depth"] != -np.inf).sum() > 5000
+    ray = E.CUDARayCastSDF(rp)
+    for i in range(5):  # (the first renders run on the small tables; the feedback of a list longer than 64 selects the large ones)
+        ray.render(scene.getHashData(), scene.getHashParams(), cp, poses[-1])
+        assert_maps_equal(ray.download(), want, f"render {i}, gradients {gradients}")
+    ray.close()
+    scene.close()
+
+
 @pytest.mark.parametrize("voxel,buckets", [(0.04, 500000), (0.01, 2000000), (0.02, 1 << 18), (0.004, 1 << 14), (0.035, 7)])
 def test_exact_shortcuts(vh, voxel, buckets):
     """div_exact == `/` and umod_fast == `%` bit for bit on 16 M pseudo-random operands"""
