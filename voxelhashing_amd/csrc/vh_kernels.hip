@@ -2341,7 +2341,27 @@ VHD void render_tile(const VhHashData& hd, const VhHashParams& hp, const VhRayCa
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (complete) {
+    // (a short list: its 7 x listed probes dealt to the lanes, a probe each per round, instead of seven in a row in the lanes that
+    // hold an entry while the others idle -- two rounds for the median list of 13 blocks)
+    constexpr uint32_t kSpreadRounds = 3;
+    const bool spread = kPerLane == 1u && complete && listed * 7u <= kSpreadRounds * kWave;
+    if (spread) {
+#pragma unroll
+        for (uint32_t r = 0; r < kSpreadRounds; r++) {
+            if (r * kWave < listed * 7u) { // (wave-uniform)
+                const uint32_t t = lane + r * kWave;
+                const uint32_t e = (t * 9363u) >> 16; // t / 7 for t < 448
+                const uint32_t j = t - 7u * e + 1u;
+                const uint32_t src = min(e, kWave - 1u);
+                const int bx = __shfl(mine[0].x, (int)src), by = __shfl(mine[0].y, (int)src), bz = __shfl(mine[0].z, (int)src);
+                const uint32_t home = (uint32_t)__shfl((int)slot[0], (int)src);
+                if (e < listed) {
+                    const int sl = Lookup::slot_find(tab, bx + (int)(j & 1u), by + (int)((j >> 1) & 1u), bz + (int)((j >> 2) & 1u));
+                    tab[home * kTileSlotWords + 3u + j] = sl >= 0 ? tab[(uint32_t)sl * kTileSlotWords + 3u] : VH_FREE_ENTRY;
+                }
+            }
+        }
+    } else if (complete) {
         // pointers of the seven neighbours a sample in this block can straddle into
 #pragma unroll
         for (uint32_t k = 0; k < kPerLane; k++) {
